@@ -1,0 +1,145 @@
+/*
+ * hypmerge.h -- C ABI of libhypmerge.so, the MI355X (gfx950) merge engine for HypTokenizer.
+ *
+ * The reference (sangaprabhav/HypTokenizer) has no FFI / plugin interface on this path: the hot
+ * path is plain Python calling PyTorch.  Each entry point below therefore
+ * cites the reference PYTHON call site it replaces; INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add at that site.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types in any signature.
+ *   - `*_dev` pointers are device addresses owned by the caller (e.g. tensor.data_ptr());
+ *     all other pointers are host memory owned by the caller.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Functions that return
+ *     results in HOST memory synchronise that stream before returning; functions that only
+ *     write device memory are asynchronous on it.
+ *   - return value: 0 = HM_OK; negative = argument / capacity error (HM_E_*); positive = hipError_t.
+ *     hm_last_error() returns a human-readable message for the last non-zero status.
+ *   - table layout handed in by the caller is the reference's: row-major fp32 [n_rows, ld],
+ *     column 0 = time coordinate, columns 1..d = spatial (tokenizer/hyperbolic_merge.py:145-153).
+ *   - sign_mode: 0 = arithmetic of the reference as shipped (u = -minkowski_dot),
+ *                1 = standard Lorentz sign (u = +minkowski_dot).
+ *   - candidate order everywhere: ascending fp32 distance, ties by row-major (i, j)
+ *     (stable sort of the nonzero() list, hyperbolic_merge.py:263-269,378; fast...:349-355,371).
+ *   - every distance is d = acosh(max(u,1)) / sqrt(c) evaluated with the canonical fp32
+ *     arithmetic of DESIGN.md; thresholds compare in fp32 (d < thr, NaN never passes).
+ */
+#ifndef HYPMERGE_H
+#define HYPMERGE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HM_ABI_VERSION 1
+
+#define HM_OK            0
+#define HM_E_ARG        (-1)   /* bad argument (null pointer, range, unsupported dimension) */
+#define HM_E_CAPACITY   (-2)   /* an internal workspace was too small for this request      */
+#define HM_E_STATE      (-3)   /* call order violated (e.g. scan before hm_set_table)        */
+#define HM_E_NOMEM      (-4)
+
+#define HM_SIGN_REFERENCE 0
+#define HM_SIGN_LORENTZ   1
+
+typedef struct hm_engine hm_engine;
+
+int         hm_abi_version(void);
+const char* hm_last_error(const hm_engine* e);          /* e may be NULL: last global error */
+
+/* One engine per device.  Allocates the scan image ([max_rows] rows) and all workspaces; nothing
+ * is allocated in the per-call path afterwards.  d1 = d + 1 (2 <= d1 <= 129).
+ * Replaces: the pre-allocated table of HyperbolicTokenizer.__init__ (hyperbolic_merge.py:144-153)
+ * as far as the search kernels are concerned, and the FAISS index objects
+ * (_init_faiss_index :593-605, _build_faiss_index fast...:195-240), which are not used at all. */
+int hm_engine_create(hm_engine** out, int device, int64_t max_rows, int d1, int sign_mode);
+int hm_engine_destroy(hm_engine* e);
+
+/* (Re)build the scan image from rows [0, n_rows) of the caller's table.  Replaces nothing in the
+ * reference (it re-reads self.embeddings[:n] every step, hyperbolic_merge.py:250). */
+int hm_set_table(hm_engine* e, const float* X_dev, int64_t ld, int64_t n_rows, void* stream);
+/* Refresh image rows [row_begin, row_end) after the caller changed those table rows. */
+int hm_update_rows(hm_engine* e, const float* X_dev, int64_t ld, int64_t row_begin, int64_t row_end,
+                   void* stream);
+int64_t hm_rows(const hm_engine* e);                     /* live rows in the image */
+
+/* K1: nearest pair.  Over all pairs i<j<n with row_begin <= i < row_end: the smallest (d, i, j)
+ * with d < thr.  *found = 0 when no pair qualifies.  Results in host memory.
+ * Replaces: _find_merge_candidates + sort + [0] of HyperbolicTokenizer.optimize_merges
+ * (hyperbolic_merge.py:371-396, candidate search :247-269). */
+int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end,
+                       float* d, int32_t* i, int32_t* j, int32_t* found, void* stream);
+
+/* K2: the k smallest candidates in order, and the exact number of candidates.
+ * d_out/i_out/j_out have room for k entries (may be NULL when k == 0); *n_out = min(k, *count).
+ * Replaces: the recompute branch of _find_merge_candidates_fast + candidates.sort() +
+ * AdaptiveMergeCache.add_batch truncation to max_size (fast_hyperbolic_merge.py:336-355,371-374,78-95). */
+int hm_pairwise_topk(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end,
+                     float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count,
+                     void* stream);
+
+/* All candidates (unordered) -- the caller sorts them row-major.  At most cap triples are written;
+ * *total is the exact number.  Replaces: the candidate list of _find_merge_candidates
+ * (hyperbolic_merge.py:247-269) when a caller really wants every tuple. */
+int hm_pairwise_candidates(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end,
+                           int64_t cap, int32_t* i_out, int32_t* j_out, float* d_out, int64_t* total,
+                           void* stream);
+
+/* K3: distances from image row `row` to image rows [0, n): d_out_dev[n] (device).
+ * No reference equivalent (incremental maintenance). */
+int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, float* d_out_dev, void* stream);
+
+/* K5: gathered pair distances on the image: out_dev[t] = d(row I[t], row J[t]).
+ * Replaces: distance(...).item() loops (_compute_distance_statistics fast...:448-455,
+ * n<=100 branch hyperbolic_merge.py:270-289). */
+int hm_pair_distance(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, int64_t b, float c,
+                     float* out_dev, void* stream);
+
+/* K4: batched "midpoint" project(exp_map(x_i, w * log_map(x_i, x_j))) on the image rows,
+ * out_dev[b, d1] in the reference's column order.
+ * Replaces: _merge_tokens arithmetic (hyperbolic_merge.py:326-340) and the loop of
+ * _evaluate_candidates_parallel (:568-587). */
+int hm_midpoint_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev,
+                      int64_t b, float c, float* out_dev, void* stream);
+
+/* Fused merge step: midpoint of image rows (i, j) with weight w is written to row `new_row` of the
+ * caller's table AND of the image; the live-row count becomes max(rows, new_row + 1).
+ * Replaces: hyperbolic_merge.py:326-351 (log_map, scale, exp_map, project, embeddings.data[n] = x). */
+int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, float c, float* X_dev, int64_t ld,
+                    int64_t new_row, void* stream);
+
+/* Dense distance block between two arbitrary device arrays: out_dev[n1, n2].
+ * Replaces: batch_distance / batch_distance_optimized (embedding/lorentz_model.py:141-210) and
+ * _compute_pairwise_distances (hyperbolic_merge.py:166-190).  Engine-independent. */
+int hm_batch_distance(const float* X_dev, int64_t n1, const float* Y_dev, int64_t n2, int64_t ld_x,
+                      int64_t ld_y, int d1, float c, int sign_mode, float* out_dev, void* stream);
+
+/* Row-wise Lorentz primitives on device arrays [b, d1] with leading dimension ld
+ * (embedding/lorentz_model.py).  Engine-independent.
+ *   hm_rows_minkowski : out[b]      = minkowski_dot(x, y)            (:14-25, sign_mode applies)
+ *   hm_rows_distance  : out[b]      = distance(x, y, c)              (:122-138)
+ *   hm_rows_log_map   : out[b, d1]  = log_map(x, y)                  (:96-119)
+ *   hm_rows_exp_map   : out[b, d1]  = exp_map(x, v)                  (:73-93)
+ *   hm_rows_project   : out[b, d1]  = project_to_hyperboloid(x, c)   (:41-56)           */
+int hm_rows_minkowski(const float* x_dev, const float* y_dev, int64_t b, int64_t ld, int d1, int sign_mode,
+                      float* out_dev, void* stream);
+int hm_rows_distance(const float* x_dev, const float* y_dev, int64_t b, int64_t ld, int d1, float c,
+                     int sign_mode, float* out_dev, void* stream);
+int hm_rows_log_map(const float* x_dev, const float* y_dev, int64_t b, int64_t ld, int d1, int sign_mode,
+                    float* out_dev, int64_t ld_out, void* stream);
+int hm_rows_exp_map(const float* x_dev, const float* v_dev, int64_t b, int64_t ld, int d1, float* out_dev,
+                    int64_t ld_out, void* stream);
+int hm_rows_project(const float* x_dev, int64_t b, int64_t ld, int d1, float c, float* out_dev,
+                    int64_t ld_out, void* stream);
+
+/* Timing of the last scan launched by hm_pairwise_argmin / hm_pairwise_topk on this engine,
+ * measured with HIP events on the stream the kernel ran on (bench.py roofline).
+ * *scan_ms = duration of the dominant pair-scan kernel launch(es); *pairs = pairs it covered. */
+int hm_last_scan_stats(const hm_engine* e, float* scan_ms, int64_t* pairs, int64_t* emitted, int32_t* passes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPMERGE_H */
