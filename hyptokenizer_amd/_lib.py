@@ -1,0 +1,94 @@
+"""ctypes binding of libhypmerge.so (C ABI declared in include/hypmerge.h).
+
+There is no CPU fallback: if the shared library is missing or fails to load, importing the
+engine raises ``HypMergeUnavailable`` with build instructions.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhypmerge.so")
+
+HM_OK = 0
+HM_E_ARG, HM_E_CAPACITY, HM_E_STATE, HM_E_NOMEM = -1, -2, -3, -4
+SIGN_REFERENCE, SIGN_LORENTZ = 0, 1
+
+#: every symbol include/hypmerge.h declares (tests check that the library exports all of them)
+EXPORTED_SYMBOLS = (
+    "hm_abi_version", "hm_last_error", "hm_engine_create", "hm_engine_destroy", "hm_set_table",
+    "hm_update_rows", "hm_rows", "hm_pairwise_argmin", "hm_pairwise_topk", "hm_pairwise_candidates",
+    "hm_row_vs_all", "hm_pair_distance", "hm_midpoint_batch", "hm_merge_append", "hm_batch_distance",
+    "hm_rows_minkowski", "hm_rows_distance", "hm_rows_log_map", "hm_rows_exp_map", "hm_rows_project",
+    "hm_last_scan_stats",
+)
+
+
+class HypMergeUnavailable(RuntimeError):
+    """libhypmerge.so could not be loaded (it must be built with hipcc for gfx950)."""
+
+
+class HypMergeError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libhypmerge status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HypMergeUnavailable(
+            f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C hyptokenizer_amd/csrc` (needs hipcc, --offload-arch=gfx950). "
+            "The merge engine has no CPU fallback.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as exc:  # missing ROCm runtime, wrong arch, ...
+        raise HypMergeUnavailable(f"cannot load {LIB_PATH}: {exc}") from exc
+
+    vp, f32, i32, i64 = C.c_void_p, C.c_float, C.c_int32, C.c_int64
+    pf32, pi32, pi64 = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+    L.hm_abi_version.restype = C.c_int
+    L.hm_last_error.restype = C.c_char_p
+    L.hm_last_error.argtypes = [vp]
+    L.hm_engine_create.argtypes = [C.POINTER(vp), C.c_int, i64, C.c_int, C.c_int]
+    L.hm_engine_destroy.argtypes = [vp]
+    L.hm_set_table.argtypes = [vp, vp, i64, i64, vp]
+    L.hm_update_rows.argtypes = [vp, vp, i64, i64, i64, vp]
+    L.hm_rows.restype = i64
+    L.hm_rows.argtypes = [vp]
+    L.hm_pairwise_argmin.argtypes = [vp, f32, f32, i64, i64, pf32, pi32, pi32, pi32, vp]
+    L.hm_pairwise_topk.argtypes = [vp, f32, f32, i64, i64, i64, vp, vp, vp, pi64, pi64, vp]
+    L.hm_pairwise_candidates.argtypes = [vp, f32, f32, i64, i64, i64, vp, vp, vp, pi64, vp]
+    L.hm_row_vs_all.argtypes = [vp, i64, i64, f32, vp, vp]
+    L.hm_pair_distance.argtypes = [vp, vp, vp, i64, f32, vp, vp]
+    L.hm_midpoint_batch.argtypes = [vp, vp, vp, vp, i64, f32, vp, vp]
+    L.hm_merge_append.argtypes = [vp, i32, i32, f32, f32, vp, i64, i64, vp]
+    L.hm_batch_distance.argtypes = [vp, i64, vp, i64, i64, i64, C.c_int, f32, C.c_int, vp, vp]
+    L.hm_rows_minkowski.argtypes = [vp, vp, i64, i64, C.c_int, C.c_int, vp, vp]
+    L.hm_rows_distance.argtypes = [vp, vp, i64, i64, C.c_int, f32, C.c_int, vp, vp]
+    L.hm_rows_log_map.argtypes = [vp, vp, i64, i64, C.c_int, C.c_int, vp, i64, vp]
+    L.hm_rows_exp_map.argtypes = [vp, vp, i64, i64, C.c_int, vp, i64, vp]
+    L.hm_rows_project.argtypes = [vp, i64, i64, C.c_int, f32, vp, i64, vp]
+    L.hm_last_scan_stats.argtypes = [vp, pf32, pi64, pi64, pi32]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("hm_last_error", "hm_rows"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(status: int, engine=None) -> None:
+    if status != HM_OK:
+        msg = load().hm_last_error(engine)
+        raise HypMergeError(status, msg.decode("utf-8", "replace") if msg else "")

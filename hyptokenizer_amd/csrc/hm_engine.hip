@@ -1,0 +1,1432 @@
+// hm_engine.hip -- gfx950 kernels and C ABI of the hyperbolic merge engine (include/hypmerge.h).
+//
+// Hot path: the all-pairs Lorentz-distance candidate search of
+// HyperbolicTokenizer._find_merge_candidates (tokenizer/hyperbolic_merge.py:247-269) and
+// FastHyperbolicTokenizer._find_merge_candidates_fast (tokenizer/fast_hyperbolic_merge.py:336-374),
+// plus the log-map / exp-map "midpoint" of _merge_tokens (hyperbolic_merge.py:326-340).
+//
+// Kernel inventory
+//   hm_scan_kernel      pair scan: X.G.X^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact
+//                       fmaf chain), A rows stationary in registers, partner rows streamed through
+//                       LDS by LDS-DMA, epilogue = prefilter on the acosh argument + wave-aggregated
+//                       emission of survivors.  Never materialises the N x N matrix.
+//   hm_post_*           exact canonical distance for the survivors, threshold test, exact
+//                       (d, i, j) selection (min / radix narrowing / rank sort).
+//   hm_midpoint_kernel  batched log-map -> scale -> exp-map -> project.
+//   hm_pairdist_kernel, hm_rowvsall_kernel, hm_dense_kernel, hm_rows_* : gathered / dense forms.
+//
+// Data layout in HBM: the "scan image" img[rows_alloc][RS] fp32, RS = 4*NG + 4, NG = groups of 4
+// spatial coordinates.  Group g holds spatial coordinates s = 4g..4g+3 in the order
+// [s0, s2, s1, s3] so that lane-half h of a wave reads ONE 8-byte word (position 2h) holding its
+// operands for the two MFMA k-steps of the group; the last group is [x0, 0, 0, 0] (time).
+// A 64-row tile of the image is one contiguous block of (NG+1) KiB.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/hypmerge.h"
+#include "hm_device_math.h"
+
+#pragma clang fp contract(off)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// constants
+// ------------------------------------------------------------------------------------------------
+#define HM_ROWS_PER_BLOCK 256      // 4 waves x 64 stationary rows
+#define HM_COLS_PER_TILE 64        // partner rows per LDS tile
+#define HM_TIE_SLACK 1024u         // ulps of u' that are treated as "may still order before" (d is 2.5-ulp monotone)
+#define HM_MODE_TOPK 0
+#define HM_MODE_ARGMIN 1
+#define HM_MODE_HIST 2
+#define HM_HIST_BINS 256
+#define HM_DIGIT_BINS 4096
+#define HM_RANK_LIMIT 49152        // rank sort is O(M^2): narrow by radix digits above this
+
+struct ScanArgs {
+    const float* img;
+    int n;                  // live rows
+    int row_begin, row_end; // i range
+    int rb_first;           // first 256-row block
+    int ct_per_chunk;       // column tiles per block
+    int nct;                // column tiles in total = ceil(n / 64)
+    float u_hi;             // candidate prefilter: u < u_hi
+    float u_lo;             // surely-below-threshold bound: u' < u_lo
+    uint32_t cut_bits;      // emit when bits(u') <= cut_bits (or not sure)
+    int tie_imax;           // entries with bits(u') == cut_bits only when i <= tie_imax
+    int thr_pos;            // thr > 0: u' == 1 gives d == 0, surely a candidate
+    uint4* ent;
+    uint32_t ent_cap;
+    uint32_t* ctr;              // [0] emitted entries
+    unsigned long long* ctr64;  // [0] sure count  [1] running best key (argmin)
+    uint32_t* hist;             // HIST mode: HM_HIST_BINS bins
+    uint32_t hist_lo;
+    uint32_t hist_shift;
+    int sample_stride;
+};
+
+// ------------------------------------------------------------------------------------------------
+// image construction
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int hm_pos_in_group(int s) { return ((s & 1) << 1) | ((s >> 1) & 1); }  // 0,2,1,3
+
+__global__ void hm_build_image_kernel(const float* __restrict__ X, int64_t ld, int d, int NG, float* __restrict__ img,
+                                      int64_t row_begin, int64_t row_end)
+{
+    const int RS = 4 * NG + 4;
+    const int64_t total = (row_end - row_begin) * RS;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = row_begin + t / RS;
+        const int p = (int)(t % RS);
+        const int g = p >> 2, q = p & 3;
+        float v = 0.0f;
+        if (g == NG) {
+            if (q == 0) v = X[row * ld];
+        } else {
+            const int s = 4 * g + (((q & 1) << 1) | (q >> 1));   // inverse of hm_pos_in_group
+            if (s < d) v = X[row * ld + 1 + s];
+        }
+        img[row * RS + p] = v;
+    }
+}
+
+__device__ __forceinline__ float hm_img_spatial(const float* img, int RS, int64_t row, int s)
+{
+    return img[row * RS + 4 * (s >> 2) + hm_pos_in_group(s & 3)];
+}
+__device__ __forceinline__ float hm_img_time(const float* img, int RS, int64_t row) { return img[row * RS + RS - 4]; }
+
+// canonical u (argument of acosh) between two image rows: spatial fmaf chain in ascending k, then time
+__device__ __forceinline__ float hm_img_u(const float* img, int RS, int d, int64_t a, int64_t b, int sign_mode)
+{
+    float acc = 0.0f;
+    for (int s = 0; s < d; ++s) acc = __builtin_fmaf(hm_img_spatial(img, RS, a, s), hm_img_spatial(img, RS, b, s), acc);
+    const float m = __builtin_fmaf(hm_img_time(img, RS, a), hm_img_time(img, RS, b), -acc);
+    return sign_mode ? m : -m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair scan
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long hm_wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t hm_wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+template <int NG, int SIGN, int MODE>
+__global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
+{
+    constexpr int RS = 4 * NG + 4;                 // floats per image row
+    constexpr int TILE_FLOATS = HM_COLS_PER_TILE * RS;
+    constexpr int NP = NG + 1;                     // 1 KiB pieces per tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 * TILE_FLOATS (+ hist)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    const int rb = p.rb_first + blockIdx.y;
+    int ct0 = blockIdx.x * p.ct_per_chunk;
+    int ct1 = ct0 + p.ct_per_chunk;
+    if (ct0 < 4 * rb) ct0 = 4 * rb;                // tiles left of the diagonal hold no i < j
+    if (ct1 > p.nct) ct1 = p.nct;
+    if (ct0 >= ct1) return;
+
+    const int i0w = rb * HM_ROWS_PER_BLOCK + wave * 64;          // first stationary row of this wave
+    const bool wave_active = (i0w < p.row_end) && (i0w + 63 >= p.row_begin) && (i0w < p.n);
+    const bool rows_full = (i0w >= p.row_begin) && (i0w + 63 < p.row_end);
+
+    uint32_t* lhist = nullptr;
+    if (MODE == HM_MODE_HIST) {
+        lhist = reinterpret_cast<uint32_t*>(smem + 2 * TILE_FLOATS);
+        for (int t = threadIdx.x; t < HM_HIST_BINS; t += 256) lhist[t] = 0;
+    }
+
+    // ---- stationary A fragments: lane (r, h) keeps its operands of every k-step in registers ----
+    float2 a[2][NP];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        const float* src = p.img + (int64_t)(i0w + 32 * tm + r) * RS + 2 * h;
+#pragma unroll
+        for (int g = 0; g < NP; ++g) a[tm][g] = *reinterpret_cast<const float2*>(src + 4 * g);
+        a[tm][NG].x = -a[tm][NG].x;                // time step: acc = S - x0*y0 = -M
+    }
+
+    // ---- LDS-DMA of one 64-row tile: NP pieces of 1 KiB, piece q handled by wave q % 4.
+    // Issued through inline asm so that hipcc does not drain it (vmcnt(0)) before the LDS reads of
+    // the tile being computed; the matching wait is the explicit vmcnt(0) in front of the barrier
+    // that ends each iteration (cdna_hip_programming.md section 5.7, LDS-DMA recipe).
+    const uint32_t lds_base = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)smem);
+    auto dma_tile = [&](int ct, int buf) {
+        const char* gsrc = reinterpret_cast<const char*>(p.img + (int64_t)ct * TILE_FLOATS) + lane * 16;
+        const uint32_t ldst = lds_base + (uint32_t)buf * (uint32_t)(TILE_FLOATS * 4);
+#pragma unroll
+        for (int q0 = 0; q0 < NP; q0 += 4) {
+            const int q = q0 + wave;
+            if (q < NP) {
+                const char* src = gsrc + q * 1024;
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(ldst + (uint32_t)q * 1024u);
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(src), "s"(dst)
+                             : "memory");
+            }
+        }
+    };
+
+    // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
+    int ct_step = 1;
+    if (MODE == HM_MODE_HIST) {
+        ct_step = p.sample_stride;
+        ct0 += (ct_step - (ct0 + rb * 7) % ct_step) % ct_step;
+        if (ct0 >= ct1) return;
+    }
+
+    dma_tile(ct0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    uint32_t sure_total = 0;         // per-lane partial of the sure count
+    int buf = 0;
+
+    for (int ct = ct0; ct < ct1; ct += ct_step, buf ^= 1) {
+        if (ct + ct_step < ct1) dma_tile(ct + ct_step, buf ^ 1);
+
+        const int j0 = ct * HM_COLS_PER_TILE;
+        const bool compute = wave_active && (j0 + 63 > i0w);
+
+        if (compute) {
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.0f;
+
+            const float* bt = smem + buf * TILE_FLOATS + r * RS + 2 * h;
+#pragma unroll
+            for (int g = 0; g < NP; ++g) {
+                const float2 b0 = *reinterpret_cast<const float2*>(bt + 4 * g);
+                const float2 b1 = *reinterpret_cast<const float2*>(bt + 32 * RS + 4 * g);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][g].x, b0.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][g].x, b1.x, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][g].x, b0.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][g].x, b1.x, acc[1][1], 0, 0, 0);
+                if (g < NG) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][g].y, b0.y, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][g].y, b1.y, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][g].y, b0.y, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][g].y, b1.y, acc[1][1], 0, 0, 0);
+                }
+            }
+            // acc = S - x0*y0 = -M.  u = -M (reference sign) = acc;  u = +M (lorentz) = -acc.
+
+            // ---- fast check: the lane's most promising u against the current bound ----
+            float ext = acc[0][0][0];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        ext = SIGN ? __builtin_fmaxf(ext, acc[tm][tn][e]) : __builtin_fminf(ext, acc[tm][tn][e]);
+            const float ext_u = SIGN ? -ext : ext;
+
+            float bound_f = p.u_hi;
+            uint32_t best_bits = 0xffffffffu, best_low = 0xffffffffu, bound_bits = hm::fbits(p.u_hi);
+            if (MODE == HM_MODE_ARGMIN) {
+                const unsigned long long gk =
+                    __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                best_bits = (uint32_t)(gk >> 32);
+                best_low = (uint32_t)gk;
+                if (best_bits != 0xffffffffu) {
+                    const uint32_t bb = best_bits + HM_TIE_SLACK + 1u;
+                    if (bb < bound_bits) { bound_bits = bb; bound_f = hm::bitsf(bb); }
+                }
+            }
+
+            if (__ballot(ext_u < bound_f) != 0ull) {
+                const bool full = rows_full && (j0 > i0w + 63) && (j0 + 63 < p.n);
+                // -------- slow path: per-element predicates, evaluated twice (count, then write).
+                // The second evaluation runs on laundered copies of the bounds so that the compiler
+                // does not keep 64 predicates alive across the wave scan (that spills).
+                uint32_t n_emit = 0, n_sure = 0;
+                unsigned long long wkey = ~0ull;
+                float bnd = bound_f;
+                uint32_t cutb = p.cut_bits;
+                uint32_t slot = 0;
+                auto visit = [&](const float w, const int tm, const int tn, const int e, const bool write) {
+                    const float u = SIGN ? -w : w;
+                    const int i = i0w + 32 * tm + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int j = j0 + 32 * tn + r;
+                    bool pass = u < bnd;
+                    if (!full) pass = pass && (i < j) && (j < p.n) && (i >= p.row_begin) && (i < p.row_end);
+                    if (!pass) return;
+                    const float up = u < 1.0f ? 1.0f : u;
+                    const uint32_t ub = hm::fbits(up);
+                    if (MODE == HM_MODE_HIST) {
+                        if (ub >= p.hist_lo) {
+                            uint32_t bin = (ub - p.hist_lo) >> p.hist_shift;
+                            if (bin > HM_HIST_BINS - 1) bin = HM_HIST_BINS - 1;
+                            atomicAdd(&lhist[bin], 1u);
+                        }
+                        return;
+                    }
+                    bool emit;
+                    uint32_t flag = 0;
+                    if (MODE == HM_MODE_TOPK) {
+                        const bool sure = (up < p.u_lo) || (p.thr_pos && ub == 0x3f800000u);
+                        if (sure && !write) ++n_sure;
+                        flag = sure ? 1u : 0u;
+                        emit = !sure || ub < cutb || (ub == cutb && i <= p.tie_imax);
+                    } else {
+                        const uint32_t low = ((uint32_t)i << 15) | ((uint32_t)j >> 2);
+                        emit = (ub != best_bits) || (low <= best_low);
+                        if (emit && !write) {
+                            const unsigned long long k = ((unsigned long long)ub << 32) | low;
+                            wkey = k < wkey ? k : wkey;
+                        }
+                    }
+                    if (!emit) return;
+                    if (!write) { ++n_emit; return; }
+                    if (slot < p.ent_cap) p.ent[slot] = make_uint4(ub, (uint32_t)i, (uint32_t)j, flag);
+                    ++slot;
+                };
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) visit(acc[tm][tn][e], tm, tn, e, false);
+
+                if (MODE != HM_MODE_HIST) {
+                    sure_total += n_sure;
+                    const uint32_t incl = hm_wave_incl_scan(n_emit, lane);
+                    const uint32_t total = __shfl(incl, 63, 64);
+                    if (total != 0) {
+                        uint32_t base = 0;
+                        if (lane == 63) base = atomicAdd(&p.ctr[0], total);
+                        base = __shfl(base, 63, 64);
+                        slot = base + incl - n_emit;
+                        asm volatile("" : "+v"(bnd), "+s"(cutb));      // opaque: no CSE with the count pass
+#pragma unroll
+                        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                                for (int e = 0; e < 16; ++e) visit(acc[tm][tn][e], tm, tn, e, true);
+                        if (MODE == HM_MODE_ARGMIN) {
+                            const unsigned long long wk = hm_wave_min_u64(wkey);
+                            if (lane == 0) atomicMin(&p.ctr64[1], wk);
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile has landed (this wave's pieces)
+        __syncthreads();                                    // ... and every wave's; all reads of buf done
+    }
+
+    if (MODE == HM_MODE_TOPK) {
+        // one 64-bit atomic per wave for the sure count
+        unsigned long long s = sure_total;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0 && s != 0) atomicAdd(&p.ctr64[0], s);
+    }
+    if (MODE == HM_MODE_HIST) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < HM_HIST_BINS; t += 256)
+            if (lhist[t]) atomicAdd(&p.hist[t], lhist[t]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// post-processing of emitted entries
+// ------------------------------------------------------------------------------------------------
+struct ArgminRec { uint32_t found, dbits, i, j; };
+
+__device__ __forceinline__ bool hm_key_less(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2)
+{
+    if (a0 != b0) return a0 < b0;
+    if (a1 != b1) return a1 < b1;
+    return a2 < b2;
+}
+
+// one block: exact distance of every entry, threshold, lexicographic min of (dbits, i, j)
+__global__ __launch_bounds__(1024) void hm_post_argmin_kernel(const uint4* __restrict__ ent, const uint32_t* __restrict__ ctr,
+                                                              uint32_t cap, float sqrt_c, float thr, ArgminRec* out)
+{
+    __shared__ uint32_t s0[1024], s1[1024], s2[1024];
+    uint32_t m = ctr[0];
+    if (m > cap) m = cap;
+    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
+    for (uint32_t t = threadIdx.x; t < m; t += 1024) {
+        const uint4 en = ent[t];
+        const float d = hm::acosh_c(hm::bitsf(en.x)) / sqrt_c;
+        if (d < thr) {
+            const uint32_t db = hm::fbits(d);
+            if (hm_key_less(db, en.y, en.z, b0, b1, b2)) { b0 = db; b1 = en.y; b2 = en.z; }
+        }
+    }
+    s0[threadIdx.x] = b0; s1[threadIdx.x] = b1; s2[threadIdx.x] = b2;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const int o = threadIdx.x + off;
+            if (hm_key_less(s0[o], s1[o], s2[o], s0[threadIdx.x], s1[threadIdx.x], s2[threadIdx.x])) {
+                s0[threadIdx.x] = s0[o]; s1[threadIdx.x] = s1[o]; s2[threadIdx.x] = s2[o];
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out->found = (s1[0] != 0xffffffffu) ? 1u : 0u;
+        out->dbits = s0[0]; out->i = s1[0]; out->j = s2[0];
+    }
+}
+
+// entries {ubits, i, j, sure} -> {dbits | 0xffffffff, i, j, ubits}; counts valid entries
+__global__ void hm_post_distance_kernel(uint4* __restrict__ ent, const uint32_t* __restrict__ ctr, uint32_t cap, float sqrt_c,
+                                        float thr, uint32_t* __restrict__ counts /* [0] valid [1] valid & !sure */)
+{
+    uint32_t m = ctr[0];
+    if (m > cap) m = cap;
+    uint32_t nv = 0, nb = 0;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
+        uint4 en = ent[t];
+        const float d = hm::acosh_c(hm::bitsf(en.x)) / sqrt_c;
+        const bool valid = d < thr;
+        nv += valid ? 1u : 0u;
+        nb += (valid && en.w == 0u) ? 1u : 0u;
+        ent[t] = make_uint4(valid ? hm::fbits(d) : 0xffffffffu, en.y, en.z, en.x);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { nv += __shfl_xor(nv, off, 64); nb += __shfl_xor(nb, off, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (nv) atomicAdd(&counts[0], nv);
+        if (nb) atomicAdd(&counts[1], nb);
+    }
+}
+
+// radix narrowing: digit `level` (0..7) of the 96-bit key (x: 12|12|8, y: 12|12|8 ... see hm_digit)
+struct Prefix { uint32_t val[3]; uint32_t mask[3]; };
+
+__device__ __host__ __forceinline__ void hm_digit_pos(int level, int& word, int& shift, int& bits)
+{
+    word = level / 3;
+    const int q = level % 3;
+    shift = q == 0 ? 20 : (q == 1 ? 8 : 0);
+    bits = q == 2 ? 8 : 12;
+}
+
+__global__ void hm_digit_hist_kernel(const uint4* __restrict__ ent, uint32_t m, Prefix pf, int level, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t lh[HM_DIGIT_BINS];
+    for (int t = threadIdx.x; t < HM_DIGIT_BINS; t += blockDim.x) lh[t] = 0;
+    __syncthreads();
+    int word, shift, bits;
+    hm_digit_pos(level, word, shift, bits);
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
+        const uint4 en = ent[t];
+        const uint32_t k[3] = {en.x, en.y, en.z};
+        if ((k[0] & pf.mask[0]) == pf.val[0] && (k[1] & pf.mask[1]) == pf.val[1] && (k[2] & pf.mask[2]) == pf.val[2])
+            atomicAdd(&lh[(k[word] >> shift) & ((1u << bits) - 1u)], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < HM_DIGIT_BINS; t += blockDim.x)
+        if (lh[t]) atomicAdd(&hist[t], lh[t]);
+}
+
+// keep entries whose masked key <= prefix (lexicographic)
+__global__ void hm_compact_prefix_kernel(const uint4* __restrict__ ent, uint32_t m, Prefix pf, uint4* __restrict__ out,
+                                         uint32_t* __restrict__ out_count, uint32_t out_cap)
+{
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
+        const uint4 en = ent[t];
+        const uint32_t a0 = en.x & pf.mask[0], a1 = en.y & pf.mask[1], a2 = en.z & pf.mask[2];
+        const bool le = !hm_key_less(pf.val[0], pf.val[1], pf.val[2], a0, a1, a2);
+        if (le) {
+            const uint32_t s = atomicAdd(out_count, 1u);
+            if (s < out_cap) out[s] = en;
+        }
+    }
+}
+
+// keep valid entries only (candidate listing)
+__global__ void hm_compact_valid_kernel(const uint4* __restrict__ ent, uint32_t m, uint4* __restrict__ out,
+                                        uint32_t* __restrict__ out_count, uint32_t out_cap)
+{
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
+        const uint4 en = ent[t];
+        if (en.x != 0xffffffffu) {
+            const uint32_t s = atomicAdd(out_count, 1u);
+            if (s < out_cap) out[s] = en;
+        }
+    }
+}
+
+// exact rank of every key among m unique keys; rank < k is written to out[rank]
+__global__ __launch_bounds__(256) void hm_rank_sort_kernel(const uint4* __restrict__ ent, uint32_t m, uint4* __restrict__ out,
+                                                           uint32_t k)
+{
+    __shared__ uint4 tile[1024];
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint4 me = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0);
+    if (t < m) me = ent[t];
+    uint32_t rank = 0;
+    for (uint32_t base = 0; base < m; base += 1024) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < 1024; q += 256) {
+            const uint32_t idx = base + q;
+            tile[q] = idx < m ? ent[idx] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0);
+        }
+        __syncthreads();
+        const uint32_t lim = (m - base) < 1024u ? (m - base) : 1024u;
+        for (uint32_t q = 0; q < lim; ++q) {
+            const uint4 o = tile[q];
+            rank += hm_key_less(o.x, o.y, o.z, me.x, me.y, me.z) ? 1u : 0u;
+        }
+    }
+    if (t < m && rank < k) out[rank] = me;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gathered / dense kernels on the image
+// ------------------------------------------------------------------------------------------------
+__global__ void hm_pairdist_kernel(const float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
+                                   const int32_t* __restrict__ J, int64_t b, float sqrt_c, int sign_mode, float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    out[t] = hm::dist_from_u(hm_img_u(img, RS, d, I[t], J[t], sign_mode), sqrt_c);
+}
+
+__global__ void hm_rowvsall_kernel(const float* __restrict__ img, int RS, int d, int64_t row, int64_t n, float sqrt_c,
+                                   int sign_mode, float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    out[t] = hm::dist_from_u(hm_img_u(img, RS, d, row, t, sign_mode), sqrt_c);
+}
+
+// midpoint of (x, y) given as accessor lambdas; writes d1 values through `put`
+template <class GX, class GY, class PUT>
+__device__ __forceinline__ void hm_midpoint_core(int d, float w, float c, int sign_mode, GX gx, GY gy, PUT put, float* scratch)
+{
+    // log_map (embedding/lorentz_model.py:96-119)
+    float acc = 0.0f;
+    for (int k = 1; k <= d; ++k) acc = __builtin_fmaf(gx(k), gy(k), acc);
+    const float mref = __builtin_fmaf(gx(0), gy(0), -acc);
+    const float u = sign_mode ? mref : -mref;
+    const float m = -u;
+    const float a = hm::clamp_min_one(u);
+    float coef = hm::acosh_c(a) / __builtin_sqrtf(a * a - 1.0f);
+    if (coef == coef && coef > 1.0e4f) coef = 1.0e4f;
+    // v = w * log ; exp_map (:73-93)
+    float n2 = 0.0f;
+    for (int k = 0; k <= d; ++k) {
+        const float v = (coef * (gy(k) + m * gx(k))) * w;
+        scratch[k] = v;
+        if (k >= 1) n2 = __builtin_fmaf(v, v, n2);
+    }
+    if (n2 == n2 && n2 < 1.0e-8f) n2 = 1.0e-8f;
+    const float nn = __builtin_sqrtf(n2);
+    const float ch = hm::cosh_c(nn), sh = hm::sinh_c(nn);
+    // project (:41-56)
+    float r2 = 0.0f;
+    for (int k = 1; k <= d; ++k) {
+        const float e = ch * gx(k) + sh * (scratch[k] / nn);
+        scratch[k] = e;
+        r2 = __builtin_fmaf(e, e, r2);
+    }
+    const float rr = __builtin_sqrtf(r2);
+    put(0, __builtin_sqrtf(1.0f + (c * rr) * rr));
+    for (int k = 1; k <= d; ++k) put(k, scratch[k]);
+}
+
+#define HM_MAX_D1 132
+
+__global__ void hm_midpoint_kernel(const float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
+                                   const int32_t* __restrict__ J, const float* __restrict__ W, int64_t b, float c,
+                                   int sign_mode, float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    float scratch[HM_MAX_D1];
+    const int64_t ri = I[t], rj = J[t];
+    auto gx = [&](int k) { return k == 0 ? hm_img_time(img, RS, ri) : hm_img_spatial(img, RS, ri, k - 1); };
+    auto gy = [&](int k) { return k == 0 ? hm_img_time(img, RS, rj) : hm_img_spatial(img, RS, rj, k - 1); };
+    float* o = out + t * (d + 1);
+    hm_midpoint_core(d, W[t], c, sign_mode, gx, gy, [&](int k, float v) { o[k] = v; }, scratch);
+}
+
+// fused merge: midpoint of image rows (i, j) -> table row and image row `new_row`
+__global__ void hm_merge_append_kernel(float* __restrict__ img, int RS, int d, int NG, int32_t i, int32_t j, float w, float c,
+                                       int sign_mode, float* __restrict__ X, int64_t ld, int64_t new_row)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float scratch[HM_MAX_D1];
+    const int64_t ri = i, rj = j;
+    auto gx = [&](int k) { return k == 0 ? hm_img_time(img, RS, ri) : hm_img_spatial(img, RS, ri, k - 1); };
+    auto gy = [&](int k) { return k == 0 ? hm_img_time(img, RS, rj) : hm_img_spatial(img, RS, rj, k - 1); };
+    float* xr = X + new_row * ld;
+    float* ir = img + new_row * RS;
+    hm_midpoint_core(d, w, c, sign_mode, gx, gy,
+                     [&](int k, float v) {
+                         xr[k] = v;
+                         if (k == 0) ir[4 * NG] = v;
+                         else ir[4 * ((k - 1) >> 2) + hm_pos_in_group((k - 1) & 3)] = v;
+                     },
+                     scratch);
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine-independent kernels on row-major arrays (embedding/lorentz_model.py function surface)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hm_rm_u(const float* x, const float* y, int d1, int sign_mode)
+{
+    float acc = 0.0f;
+    for (int k = 1; k < d1; ++k) acc = __builtin_fmaf(x[k], y[k], acc);
+    const float m = __builtin_fmaf(x[0], y[0], -acc);
+    return sign_mode ? m : -m;
+}
+
+__global__ void hm_dense_kernel(const float* __restrict__ X, int64_t n1, const float* __restrict__ Y, int64_t n2, int64_t ldx,
+                                int64_t ldy, int d1, float sqrt_c, int sign_mode, float* __restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= n2 || i >= n1) return;
+    out[i * n2 + j] = hm::dist_from_u(hm_rm_u(X + i * ldx, Y + j * ldy, d1, sign_mode), sqrt_c);
+}
+
+__global__ void hm_rows_minkowski_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t b, int64_t ld, int d1,
+                                         int sign_mode, float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    // minkowski_dot under the active convention = -u
+    out[t] = -hm_rm_u(x + t * ld, y + t * ld, d1, sign_mode);
+}
+
+__global__ void hm_rows_distance_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t b, int64_t ld, int d1,
+                                        float sqrt_c, int sign_mode, float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    out[t] = hm::dist_from_u(hm_rm_u(x + t * ld, y + t * ld, d1, sign_mode), sqrt_c);
+}
+
+__global__ void hm_rows_log_map_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t b, int64_t ld, int d1,
+                                       int sign_mode, float* __restrict__ out, int64_t ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    const float* xr = x + t * ld;
+    const float* yr = y + t * ld;
+    const float u = hm_rm_u(xr, yr, d1, sign_mode);
+    const float m = -u;
+    const float a = hm::clamp_min_one(u);
+    float coef = hm::acosh_c(a) / __builtin_sqrtf(a * a - 1.0f);
+    if (coef == coef && coef > 1.0e4f) coef = 1.0e4f;
+    for (int k = 0; k < d1; ++k) out[t * ldo + k] = coef * (yr[k] + m * xr[k]);
+}
+
+__global__ void hm_rows_exp_map_kernel(const float* __restrict__ x, const float* __restrict__ v, int64_t b, int64_t ld, int d1,
+                                       float* __restrict__ out, int64_t ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    const float* xr = x + t * ld;
+    const float* vr = v + t * ld;
+    float n2 = 0.0f;
+    for (int k = 1; k < d1; ++k) n2 = __builtin_fmaf(vr[k], vr[k], n2);
+    if (n2 == n2 && n2 < 1.0e-8f) n2 = 1.0e-8f;
+    const float nn = __builtin_sqrtf(n2);
+    const float ch = hm::cosh_c(nn), sh = hm::sinh_c(nn);
+    for (int k = 0; k < d1; ++k) out[t * ldo + k] = ch * xr[k] + sh * (vr[k] / nn);
+}
+
+__global__ void hm_rows_project_kernel(const float* __restrict__ x, int64_t b, int64_t ld, int d1, float c, float* __restrict__ out,
+                                       int64_t ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    const float* xr = x + t * ld;
+    float r2 = 0.0f;
+    for (int k = 1; k < d1; ++k) r2 = __builtin_fmaf(xr[k], xr[k], r2);
+    const float rr = __builtin_sqrtf(r2);
+    const float x0 = __builtin_sqrtf(1.0f + (c * rr) * rr);
+    for (int k = 1; k < d1; ++k) out[t * ldo + k] = xr[k];
+    out[t * ldo] = x0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+struct HostCtl {                 // pinned host mirror of small device results
+    uint32_t ctr[4];             // [0] emitted [1] valid [2] valid & !sure [3] compacted
+    unsigned long long ctr64[2]; // [0] sure count [1] argmin key
+    ArgminRec rec;
+    uint32_t hist[HM_DIGIT_BINS];
+};
+
+struct hm_engine {
+    int device = 0;
+    int64_t max_rows = 0, rows_alloc = 0, n = 0;
+    int d1 = 0, d = 0, NG = 0, RS = 0, sign_mode = 0;
+    float* img = nullptr;
+    uint4* ent = nullptr;
+    uint4* ent2 = nullptr;
+    uint4* sorted = nullptr;
+    uint32_t ent_cap = 0;
+    uint32_t* d_ctr = nullptr;            // 4 x u32
+    unsigned long long* d_ctr64 = nullptr; // 2 x u64
+    ArgminRec* d_rec = nullptr;
+    uint32_t* d_hist = nullptr;           // HM_DIGIT_BINS
+    HostCtl* h = nullptr;                 // pinned
+    uint4* h_sorted = nullptr;            // pinned, sorted_cap entries
+    uint32_t sorted_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // cut prediction for top-k: valid while rows are only appended
+    bool have_cut = false;
+    uint32_t last_cut_bits = 0;
+    int64_t last_cut_k = 0;
+    float last_cut_c = 0.f;
+    // stats
+    float last_scan_ms = 0.f;
+    int64_t last_pairs = 0, last_emitted = 0;
+    int last_passes = 0;
+    std::string err;
+};
+
+static int hm_fail(hm_engine* e, int code, const std::string& msg)
+{
+    g_last_error = msg;
+    if (e) e->err = msg;
+    return code;
+}
+
+#define HM_HIP(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t _st = (call);                                                                      \
+        if (_st != hipSuccess)                                                                        \
+            return hm_fail(e, (int)_st, std::string(#call) + ": " + hipGetErrorString(_st));          \
+    } while (0)
+
+static const int kSupportedNG[] = {1, 2, 3, 4, 6, 8, 10, 13, 16, 20, 25, 28, 32};
+
+static int hm_pick_ng(int d)
+{
+    const int need = (d + 3) / 4;
+    for (int v : kSupportedNG)
+        if (v >= need) return v;
+    return -1;
+}
+
+extern "C" int hm_abi_version(void) { return HM_ABI_VERSION; }
+
+extern "C" const char* hm_last_error(const hm_engine* e)
+{
+    if (e && !e->err.empty()) return e->err.c_str();
+    return g_last_error.c_str();
+}
+
+extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, int d1, int sign_mode)
+{
+    hm_engine* e = nullptr;
+    if (!out) return hm_fail(nullptr, HM_E_ARG, "hm_engine_create: out is NULL");
+    *out = nullptr;
+    if (d1 < 2 || d1 > 129) return hm_fail(nullptr, HM_E_ARG, "hm_engine_create: d1 must be in [2, 129]");
+    if (max_rows < 2 || max_rows > 131072)
+        return hm_fail(nullptr, HM_E_ARG, "hm_engine_create: max_rows must be in [2, 131072]");
+    if (sign_mode != 0 && sign_mode != 1) return hm_fail(nullptr, HM_E_ARG, "hm_engine_create: sign_mode must be 0 or 1");
+    int ndev = 0;
+    hipError_t st = hipGetDeviceCount(&ndev);
+    if (st != hipSuccess || ndev <= 0)
+        return hm_fail(nullptr, st != hipSuccess ? (int)st : (int)hipErrorNoDevice,
+                       "hm_engine_create: no HIP device available (the merge engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return hm_fail(nullptr, HM_E_ARG, "hm_engine_create: bad device index");
+    e = new hm_engine();
+    e->device = device;
+    e->max_rows = max_rows;
+    e->d1 = d1;
+    e->d = d1 - 1;
+    e->NG = hm_pick_ng(e->d);
+    e->RS = 4 * e->NG + 4;
+    e->sign_mode = sign_mode;
+    e->rows_alloc = (max_rows + HM_ROWS_PER_BLOCK - 1) / HM_ROWS_PER_BLOCK * HM_ROWS_PER_BLOCK + HM_ROWS_PER_BLOCK;
+    e->ent_cap = 1u << 24;
+    e->sorted_cap = 1u << 16;
+    HM_HIP(hipSetDevice(device));
+    HM_HIP(hipMalloc(&e->img, sizeof(float) * (size_t)e->rows_alloc * e->RS));
+    HM_HIP(hipMemset(e->img, 0, sizeof(float) * (size_t)e->rows_alloc * e->RS));
+    HM_HIP(hipMalloc(&e->ent, sizeof(uint4) * (size_t)e->ent_cap));
+    HM_HIP(hipMalloc(&e->ent2, sizeof(uint4) * (size_t)e->ent_cap));
+    HM_HIP(hipMalloc(&e->sorted, sizeof(uint4) * (size_t)e->sorted_cap));
+    HM_HIP(hipMalloc(&e->d_ctr, sizeof(uint32_t) * 4));
+    HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 2));
+    HM_HIP(hipMalloc(&e->d_rec, sizeof(ArgminRec)));
+    HM_HIP(hipMalloc(&e->d_hist, sizeof(uint32_t) * HM_DIGIT_BINS));
+    HM_HIP(hipHostMalloc(&e->h, sizeof(HostCtl), hipHostMallocDefault));
+    HM_HIP(hipHostMalloc(&e->h_sorted, sizeof(uint4) * (size_t)e->sorted_cap, hipHostMallocDefault));
+    HM_HIP(hipEventCreate(&e->ev0));
+    HM_HIP(hipEventCreate(&e->ev1));
+    *out = e;
+    return HM_OK;
+}
+
+extern "C" int hm_engine_destroy(hm_engine* e)
+{
+    if (!e) return HM_OK;
+    (void)hipSetDevice(e->device);
+    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist};
+    for (void* q : dev_ptrs) (void)hipFree(q);
+    if (e->h) (void)hipHostFree(e->h);
+    if (e->h_sorted) (void)hipHostFree(e->h_sorted);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    delete e;
+    return HM_OK;
+}
+
+extern "C" int64_t hm_rows(const hm_engine* e) { return e ? e->n : -1; }
+
+static int hm_build_rows(hm_engine* e, const float* X, int64_t ld, int64_t r0, int64_t r1, hipStream_t s)
+{
+    if (r1 <= r0) return HM_OK;
+    const int64_t total = (r1 - r0) * e->RS;
+    int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(hm_build_image_kernel, dim3(blocks), dim3(256), 0, s, X, ld, e->d, e->NG, e->img, r0, r1);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_set_table(hm_engine* e, const float* X_dev, int64_t ld, int64_t n_rows, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_set_table: engine is NULL");
+    if (!X_dev || ld < e->d1 || n_rows < 0 || n_rows > e->max_rows)
+        return hm_fail(e, HM_E_ARG, "hm_set_table: bad table pointer / ld / n_rows");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    if (e->n > n_rows)   // rows that are no longer live must read as zeros (never candidates: masked)
+        HM_HIP(hipMemsetAsync(e->img + n_rows * e->RS, 0, sizeof(float) * (size_t)(e->n - n_rows) * e->RS, s));
+    int rc = hm_build_rows(e, X_dev, ld, 0, n_rows, s);
+    if (rc) return rc;
+    e->n = n_rows;
+    e->have_cut = false;
+    return HM_OK;
+}
+
+extern "C" int hm_update_rows(hm_engine* e, const float* X_dev, int64_t ld, int64_t row_begin, int64_t row_end, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_update_rows: engine is NULL");
+    if (!X_dev || ld < e->d1 || row_begin < 0 || row_end < row_begin || row_end > e->max_rows)
+        return hm_fail(e, HM_E_ARG, "hm_update_rows: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    int rc = hm_build_rows(e, X_dev, ld, row_begin, row_end, (hipStream_t)stream);
+    if (rc) return rc;
+    if (row_begin < e->n) e->have_cut = false;       // an existing row changed: cut prediction void
+    if (row_end > e->n) e->n = row_end;
+    return HM_OK;
+}
+
+// ---- threshold bounds in the u domain (double precision on the host) ----
+struct Bounds { float u_hi, u_lo; bool none; int thr_pos; };
+
+static Bounds hm_bounds(float thr, float c)
+{
+    Bounds b;
+    b.none = !(thr > 0.0f);          // d >= 0 always: nothing is below a non-positive / NaN threshold
+    b.thr_pos = thr > 0.0f ? 1 : 0;
+    b.u_hi = 1.0f; b.u_lo = 1.0f;
+    if (b.none) return b;
+    const double sc = (double)sqrtf(c);
+    const double a = (double)thr * sc;
+    const double uh = cosh(a * (1.0 + 1e-5) + 1e-300);
+    if (!(uh < 3.0e38)) {
+        b.u_hi = INFINITY;
+    } else {
+        float f = (float)uh;
+        if ((double)f < uh) f = nextafterf(f, INFINITY);
+        f = nextafterf(nextafterf(f, INFINITY), INFINITY);
+        b.u_hi = f;
+    }
+    const double ul = cosh(a * (1.0 - 1e-5));
+    if (!(ul < 3.0e38)) {
+        b.u_lo = 3.0e38f;
+    } else {
+        float f = (float)ul;
+        if ((double)f > ul) f = nextafterf(f, 0.0f);
+        f = nextafterf(nextafterf(f, 0.0f), 0.0f);
+        b.u_lo = f < 1.0f ? 1.0f : f;
+    }
+    return b;
+}
+
+template <int NG, int SIGN, int MODE>
+static hipError_t hm_launch_scan_t(const ScanArgs& a, dim3 grid, hipStream_t s)
+{
+    size_t lds = sizeof(float) * 2 * HM_COLS_PER_TILE * (4 * NG + 4);
+    if (MODE == HM_MODE_HIST) lds += sizeof(uint32_t) * HM_HIST_BINS;
+    static bool attr_set = false;    // per instantiation
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(&hm_scan_kernel<NG, SIGN, MODE>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (st != hipSuccess) return st;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE>), grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int NG>
+static hipError_t hm_launch_scan_ng(int sign, int mode, const ScanArgs& a, dim3 grid, hipStream_t s)
+{
+    if (sign) {
+        if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 1, HM_MODE_TOPK>(a, grid, s);
+        if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 1, HM_MODE_ARGMIN>(a, grid, s);
+        return hm_launch_scan_t<NG, 1, HM_MODE_HIST>(a, grid, s);
+    }
+    if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 0, HM_MODE_TOPK>(a, grid, s);
+    if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 0, HM_MODE_ARGMIN>(a, grid, s);
+    return hm_launch_scan_t<NG, 0, HM_MODE_HIST>(a, grid, s);
+}
+
+static hipError_t hm_launch_scan(const hm_engine* e, int mode, const ScanArgs& a, dim3 grid, hipStream_t s)
+{
+    switch (e->NG) {
+        case 1: return hm_launch_scan_ng<1>(e->sign_mode, mode, a, grid, s);
+        case 2: return hm_launch_scan_ng<2>(e->sign_mode, mode, a, grid, s);
+        case 3: return hm_launch_scan_ng<3>(e->sign_mode, mode, a, grid, s);
+        case 4: return hm_launch_scan_ng<4>(e->sign_mode, mode, a, grid, s);
+        case 6: return hm_launch_scan_ng<6>(e->sign_mode, mode, a, grid, s);
+        case 8: return hm_launch_scan_ng<8>(e->sign_mode, mode, a, grid, s);
+        case 10: return hm_launch_scan_ng<10>(e->sign_mode, mode, a, grid, s);
+        case 13: return hm_launch_scan_ng<13>(e->sign_mode, mode, a, grid, s);
+        case 16: return hm_launch_scan_ng<16>(e->sign_mode, mode, a, grid, s);
+        case 20: return hm_launch_scan_ng<20>(e->sign_mode, mode, a, grid, s);
+        case 25: return hm_launch_scan_ng<25>(e->sign_mode, mode, a, grid, s);
+        case 28: return hm_launch_scan_ng<28>(e->sign_mode, mode, a, grid, s);
+        case 32: return hm_launch_scan_ng<32>(e->sign_mode, mode, a, grid, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// common argument preparation; returns false when the row range is empty
+static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t row_end, ScanArgs& a, dim3& grid)
+{
+    if (row_end < 0 || row_end > e->n) row_end = e->n;
+    if (row_begin < 0) row_begin = 0;
+    if (row_end > e->n - 1) row_end = e->n - 1;        // the last row has no partner j > i
+    if (row_begin >= row_end) return false;
+    memset(&a, 0, sizeof(a));
+    a.img = e->img;
+    a.n = (int)e->n;
+    a.row_begin = (int)row_begin;
+    a.row_end = (int)row_end;
+    a.rb_first = (int)(row_begin / HM_ROWS_PER_BLOCK);
+    a.nct = (int)((e->n + HM_COLS_PER_TILE - 1) / HM_COLS_PER_TILE);
+    a.u_hi = b.u_hi;
+    a.u_lo = b.u_lo;
+    a.thr_pos = b.thr_pos;
+    a.cut_bits = 0xffffffffu;
+    a.tie_imax = 0x7fffffff;
+    a.ent = e->ent;
+    a.ent_cap = e->ent_cap;
+    a.ctr = e->d_ctr;
+    a.ctr64 = e->d_ctr64;
+    a.hist = e->d_hist;
+    a.sample_stride = 1;
+    const int nrb = (int)((row_end - 1) / HM_ROWS_PER_BLOCK) - a.rb_first + 1;
+    // column tiles per block: keep >= ~2048 blocks in flight for large tables, amortise the
+    // stationary-row load for small ones
+    int ch = 32;
+    while (ch > 4 && (int64_t)nrb * ((a.nct + ch - 1) / ch) < 1024) ch >>= 1;
+    a.ct_per_chunk = ch;
+    grid = dim3((unsigned)((a.nct + ch - 1) / ch), (unsigned)nrb, 1);
+    return true;
+}
+
+static int64_t hm_pairs_in_range(int64_t n, int64_t r0, int64_t r1)
+{
+    // sum_{i=r0}^{r1-1} (n - 1 - i)
+    const int64_t cnt = r1 - r0;
+    return cnt * (n - 1) - (r0 + r1 - 1) * cnt / 2;
+}
+
+extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end, float* d, int32_t* i,
+                                  int32_t* j, int32_t* found, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pairwise_argmin: engine is NULL");
+    if (!d || !i || !j || !found) return hm_fail(e, HM_E_ARG, "hm_pairwise_argmin: NULL output pointer");
+    if (!(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pairwise_argmin: curvature must be > 0");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    *found = 0; *d = 0.f; *i = -1; *j = -1;
+    e->last_scan_ms = 0.f; e->last_pairs = 0; e->last_emitted = 0; e->last_passes = 0;
+    const Bounds b = hm_bounds(thr, c);
+    ScanArgs a; dim3 grid;
+    if (b.none || e->n < 2 || !hm_prepare_scan(e, b, row_begin, row_end, a, grid)) return HM_OK;
+    const float sqrt_c = sqrtf(c);
+    for (int pass = 0; pass < 2; ++pass) {
+        HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 4, s));
+        HM_HIP(hipMemsetAsync(e->d_ctr64, 0xff, sizeof(unsigned long long) * 2, s));
+        HM_HIP(hipEventRecord(e->ev0, s));
+        HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s));
+        HM_HIP(hipEventRecord(e->ev1, s));
+        hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(1), dim3(1024), 0, s, e->ent, e->d_ctr, e->ent_cap, sqrt_c, thr, e->d_rec);
+        HM_HIP(hipGetLastError());
+        HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
+        HM_HIP(hipMemcpyAsync(e->h->ctr, e->d_ctr, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_ctr64, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipStreamSynchronize(s));
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e->ev0, e->ev1);
+        e->last_scan_ms += ms;
+        e->last_passes += 1;
+        e->last_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
+        e->last_emitted = e->h->ctr[0];
+        if (e->h->ctr[0] <= e->ent_cap) break;
+        // overflow: the running best key is exact (every surviving wave published it); rerun with
+        // the final bound as a static start so that only the tie band is emitted
+        if (pass == 1) return hm_fail(e, HM_E_CAPACITY, "hm_pairwise_argmin: emission buffer overflow on the bounded pass");
+        const uint32_t best_bits = (uint32_t)(e->h->ctr64[1] >> 32);
+        uint32_t bb = best_bits + HM_TIE_SLACK + 1u;
+        union { uint32_t u; float f; } cv; cv.u = bb;
+        if (cv.f < a.u_hi) a.u_hi = cv.f;
+    }
+    if (e->h->rec.found) {
+        union { uint32_t u; float f; } cv; cv.u = e->h->rec.dbits;
+        *found = 1; *d = cv.f; *i = (int32_t)e->h->rec.i; *j = (int32_t)e->h->rec.j;
+    }
+    return HM_OK;
+}
+
+// exact selection of the k smallest keys among m entries of `src` (keys unique; invalid = 0xffffffff)
+// result in e->sorted / e->h_sorted.  `other` is scratch of the same capacity.
+static int hm_select_sorted(hm_engine* e, uint4* src, uint4* other, uint32_t m, uint32_t k, hipStream_t s)
+{
+    if (k == 0 || m == 0) return HM_OK;
+    if (k > e->sorted_cap) return hm_fail(e, HM_E_CAPACITY, "top-k: k exceeds the engine's sorted capacity (65536)");
+    uint4* cur = src;
+    uint32_t mcur = m;
+    const uint32_t rank_limit = std::min<uint32_t>(HM_RANK_LIMIT, std::max<uint32_t>(2u * k, 8192u));
+    if (mcur > rank_limit) {
+        // radix narrowing on the 96-bit key, 12/12/8-bit digits per word
+        Prefix pf; memset(&pf, 0, sizeof(pf));
+        uint32_t below = 0;      // keys strictly below the prefix: certainly selected
+        int level = 0;
+        for (; level < 9; ++level) {
+            int word, shift, bits;
+            hm_digit_pos(level, word, shift, bits);
+            HM_HIP(hipMemsetAsync(e->d_hist, 0, sizeof(uint32_t) * HM_DIGIT_BINS, s));
+            hipLaunchKernelGGL(hm_digit_hist_kernel, dim3(1024), dim3(256), 0, s, cur, mcur, pf, level, e->d_hist);
+            HM_HIP(hipGetLastError());
+            HM_HIP(hipMemcpyAsync(e->h->hist, e->d_hist, sizeof(uint32_t) * HM_DIGIT_BINS, hipMemcpyDeviceToHost, s));
+            HM_HIP(hipStreamSynchronize(s));
+            const uint32_t nb = 1u << bits;
+            uint32_t cum = below, dsel = nb - 1, match = 0;
+            for (uint32_t q = 0; q < nb; ++q) {
+                if (cum + e->h->hist[q] >= k) { dsel = q; match = e->h->hist[q]; break; }
+                cum += e->h->hist[q];
+            }
+            below = cum;
+            pf.val[word] |= dsel << shift;
+            pf.mask[word] |= ((1u << bits) - 1u) << shift;
+            if (below + match <= rank_limit) break;
+        }
+        HM_HIP(hipMemsetAsync(e->d_ctr + 3, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL(hm_compact_prefix_kernel, dim3(1024), dim3(256), 0, s, cur, mcur, pf, other, e->d_ctr + 3, e->ent_cap);
+        HM_HIP(hipGetLastError());
+        HM_HIP(hipMemcpyAsync(&e->h->ctr[3], e->d_ctr + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HM_HIP(hipStreamSynchronize(s));
+        cur = other;
+        mcur = e->h->ctr[3];
+        if (mcur > 4u * HM_RANK_LIMIT) return hm_fail(e, HM_E_CAPACITY, "top-k: radix narrowing did not converge");
+    }
+    hipLaunchKernelGGL(hm_rank_sort_kernel, dim3((mcur + 255) / 256), dim3(256), 0, s, cur, mcur, e->sorted, k);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+// Choose an emission cut from sampled histograms of bits(u') so that roughly `target` entries
+// (and certainly not more than the buffer holds) are emitted.  Pure performance heuristic: the
+// caller verifies the outcome and widens the cut when fewer than k valid entries came back.
+static int hm_estimate_cut(hm_engine* e, ScanArgs a, dim3 grid, int64_t target, uint32_t* cut_bits, int* tie_imax,
+                           hipStream_t s)
+{
+    *cut_bits = 0xffffffffu;
+    *tie_imax = 0x7fffffff;
+    const int64_t pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
+    if (pairs <= (int64_t)e->ent_cap / 2) return HM_OK;           // everything fits: emit all candidates
+    union { uint32_t u; float f; } hi; hi.f = a.u_hi;
+    uint32_t lo_bits = 0x3f800000u;
+    uint32_t hi_bits = hi.f == INFINITY ? 0x7f800000u : hi.u;
+    int stride = 1;
+    while (stride < 64 && pairs / (stride * 2) > 40000000) stride *= 2;
+    double base = 0.0;               // estimated entries below the current zoom window
+    for (int zoom = 0; zoom < 6; ++zoom) {
+        uint32_t span = hi_bits - lo_bits;
+        uint32_t shift = 0;
+        while ((span >> shift) > HM_HIST_BINS) ++shift;
+        a.hist_lo = lo_bits;
+        a.hist_shift = shift;
+        a.sample_stride = stride;
+        HM_HIP(hipMemsetAsync(e->d_hist, 0, sizeof(uint32_t) * HM_DIGIT_BINS, s));
+        HM_HIP(hm_launch_scan(e, HM_MODE_HIST, a, grid, s));
+        HM_HIP(hipMemcpyAsync(e->h->hist, e->d_hist, sizeof(uint32_t) * HM_HIST_BINS, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipStreamSynchronize(s));
+        e->last_passes += 1;
+        double cum = base;
+        int bsel = -1;
+        for (int q = 0; q < HM_HIST_BINS; ++q) {
+            cum += (double)e->h->hist[q] * stride;
+            if (cum >= (double)target) { bsel = q; break; }
+        }
+        if (bsel < 0) return HM_OK;                                 // fewer than target below u_hi: emit all
+        const double before = cum - (double)e->h->hist[bsel] * stride;
+        const uint32_t edge_lo = lo_bits + ((uint32_t)bsel << shift);
+        const uint32_t edge_hi = lo_bits + (((uint32_t)bsel + 1u) << shift);   // exclusive
+        if (cum <= (double)e->ent_cap * 0.5 || shift == 0) {
+            *cut_bits = edge_hi - 1u;
+            if (cum > (double)e->ent_cap * 0.5) {
+                // a single value of u' holds more entries than the buffer: tie flood.  Emit the tie
+                // value only for the first rows; rows are visited in row-major order by the selection.
+                // estimate rows needed from the average ties per row
+                const double per_row = ((double)e->h->hist[bsel] * stride) / (double)(a.row_end - a.row_begin);
+                double rows = ((double)target - before) / (per_row > 1e-9 ? per_row : 1e-9);
+                int64_t imax = a.row_begin + (int64_t)(rows * 2.0) + 64;
+                if (imax > a.row_end) imax = a.row_end;
+                *tie_imax = (int)imax;
+            }
+            return HM_OK;
+        }
+        lo_bits = edge_lo;
+        hi_bits = edge_hi;
+        base = before;
+    }
+    return HM_OK;
+}
+
+static int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, bool list_all,
+                        int64_t* n_valid_emitted, int64_t* count, uint4** result_dev, hipStream_t s)
+{
+    *n_valid_emitted = 0;
+    *count = 0;
+    *result_dev = nullptr;
+    e->last_scan_ms = 0.f; e->last_pairs = 0; e->last_emitted = 0; e->last_passes = 0;
+    const Bounds b = hm_bounds(thr, c);
+    ScanArgs a; dim3 grid;
+    if (b.none || e->n < 2 || !hm_prepare_scan(e, b, row_begin, row_end, a, grid)) return HM_OK;
+    const float sqrt_c = sqrtf(c);
+    const bool whole = (a.row_begin == 0 && a.row_end == e->n - 1);
+
+    uint32_t cut_bits = 0xffffffffu;
+    int tie_imax = 0x7fffffff;
+    if (!list_all) {
+        if (whole && e->have_cut && e->last_cut_k >= k && e->last_cut_c == c) {
+            cut_bits = e->last_cut_bits + HM_TIE_SLACK;
+        } else {
+            int rc = hm_estimate_cut(e, a, grid, 4 * k + 4096, &cut_bits, &tie_imax, s);
+            if (rc) return rc;
+        }
+    }
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        a.cut_bits = cut_bits;
+        a.tie_imax = tie_imax;
+        HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 4, s));
+        HM_HIP(hipMemsetAsync(e->d_ctr64, 0, sizeof(unsigned long long) * 2, s));
+        HM_HIP(hipEventRecord(e->ev0, s));
+        HM_HIP(hm_launch_scan(e, HM_MODE_TOPK, a, grid, s));
+        HM_HIP(hipEventRecord(e->ev1, s));
+        hipLaunchKernelGGL(hm_post_distance_kernel, dim3(512), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, sqrt_c, thr,
+                           e->d_ctr + 1);
+        HM_HIP(hipGetLastError());
+        HM_HIP(hipMemcpyAsync(e->h->ctr, e->d_ctr, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_ctr64, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipStreamSynchronize(s));
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e->ev0, e->ev1);
+        e->last_scan_ms += ms;
+        e->last_passes += 1;
+        e->last_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
+        e->last_emitted = e->h->ctr[0];
+        const uint64_t emitted = e->h->ctr[0];
+        const bool overflow = emitted > e->ent_cap;
+        const int64_t total = (int64_t)e->h->ctr64[0] + (int64_t)e->h->ctr[2];   // sure + valid borderline
+        const int64_t valid = e->h->ctr[1];
+        const bool emitted_all = (cut_bits == 0xffffffffu);
+        if (overflow) {
+            if (list_all) return hm_fail(e, HM_E_CAPACITY, "candidate listing: more candidates than the emission buffer holds");
+            // estimate was too generous (or none was made): estimate with a smaller target
+            int rc = hm_estimate_cut(e, a, grid, std::max<int64_t>((2 * k + 1024) >> attempt, k + 64), &cut_bits, &tie_imax, s);
+            if (rc) return rc;
+            if (cut_bits == 0xffffffffu) return hm_fail(e, HM_E_CAPACITY, "top-k: could not bound the emission");
+            continue;
+        }
+        const int64_t want = std::min<int64_t>(k, total);
+        if (!emitted_all && valid < want) {
+            // the cut was too tight: widen geometrically in the ulp domain and retry
+            if (tie_imax != 0x7fffffff) {
+                tie_imax = tie_imax >= a.row_end ? 0x7fffffff : (int)std::min<int64_t>((int64_t)tie_imax * 4 + 256, a.row_end);
+                if (tie_imax >= a.row_end) tie_imax = 0x7fffffff;
+            } else {
+                const uint32_t span = cut_bits - 0x3f800000u;
+                const uint64_t nb = (uint64_t)cut_bits + std::max<uint32_t>(span, 1024u);
+                cut_bits = nb >= 0x7f800000ull ? 0xffffffffu : (uint32_t)nb;
+            }
+            continue;
+        }
+        *count = total;
+        *n_valid_emitted = valid;
+        *result_dev = e->ent;
+        return HM_OK;
+    }
+    return hm_fail(e, HM_E_CAPACITY, "top-k: emission cut did not converge");
+}
+
+extern "C" int hm_pairwise_topk(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, float* d_out,
+                                int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pairwise_topk: engine is NULL");
+    if (!n_out || !count || k < 0 || (k > 0 && (!d_out || !i_out || !j_out)))
+        return hm_fail(e, HM_E_ARG, "hm_pairwise_topk: bad output pointers / k");
+    if (!(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pairwise_topk: curvature must be > 0");
+    if (k > (int64_t)e->sorted_cap) return hm_fail(e, HM_E_CAPACITY, "hm_pairwise_topk: k > 65536");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    *n_out = 0; *count = 0;
+    int64_t valid = 0, total = 0;
+    uint4* res = nullptr;
+    int rc = hm_topk_core(e, c, thr, k, row_begin, row_end, false, &valid, &total, &res, s);
+    if (rc) return rc;
+    *count = total;
+    const uint32_t kk = (uint32_t)std::min<int64_t>(k, valid);
+    if (kk == 0 || !res) return HM_OK;
+    const uint32_t m = (uint32_t)std::min<uint64_t>(e->h->ctr[0], e->ent_cap);
+    rc = hm_select_sorted(e, res, e->ent2, m, kk, s);
+    if (rc) return rc;
+    HM_HIP(hipMemcpyAsync(e->h_sorted, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToHost, s));
+    HM_HIP(hipStreamSynchronize(s));
+    for (uint32_t t = 0; t < kk; ++t) {
+        union { uint32_t u; float f; } cv; cv.u = e->h_sorted[t].x;
+        d_out[t] = cv.f; i_out[t] = (int32_t)e->h_sorted[t].y; j_out[t] = (int32_t)e->h_sorted[t].z;
+    }
+    *n_out = kk;
+    // remember the u' of the k-th entry: while rows are only appended, the k-th smallest key can
+    // only move down, so this cut (+ tie slack) is a guaranteed superset for the next refresh
+    if (kk == k && row_begin <= 0 && (row_end < 0 || row_end >= e->n - 1)) {
+        e->have_cut = true;
+        e->last_cut_bits = e->h_sorted[kk - 1].w;
+        // entries are ordered by distance, not by u': take the max u' bits over the selection
+        uint32_t mx = 0;
+        for (uint32_t t = 0; t < kk; ++t) mx = std::max(mx, e->h_sorted[t].w);
+        e->last_cut_bits = mx;
+        e->last_cut_k = k;
+        e->last_cut_c = c;
+    } else {
+        e->have_cut = false;
+    }
+    return HM_OK;
+}
+
+extern "C" int hm_pairwise_candidates(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end, int64_t cap,
+                                      int32_t* i_out, int32_t* j_out, float* d_out, int64_t* total, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pairwise_candidates: engine is NULL");
+    if (!total || cap < 0 || (cap > 0 && (!i_out || !j_out || !d_out)))
+        return hm_fail(e, HM_E_ARG, "hm_pairwise_candidates: bad output pointers");
+    if (!(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pairwise_candidates: curvature must be > 0");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    *total = 0;
+    int64_t valid = 0, cnt = 0;
+    uint4* res = nullptr;
+    int rc = hm_topk_core(e, c, thr, 0, row_begin, row_end, true, &valid, &cnt, &res, s);
+    if (rc) return rc;
+    *total = cnt;
+    if (!res || valid == 0 || cap == 0) return HM_OK;
+    const uint32_t m = (uint32_t)std::min<uint64_t>(e->h->ctr[0], e->ent_cap);
+    HM_HIP(hipMemsetAsync(e->d_ctr + 3, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(hm_compact_valid_kernel, dim3(1024), dim3(256), 0, s, res, m, e->ent2, e->d_ctr + 3, e->ent_cap);
+    HM_HIP(hipGetLastError());
+    const int64_t ncopy = std::min<int64_t>(valid, cap);
+    std::vector<uint4> host((size_t)ncopy);
+    HM_HIP(hipMemcpyAsync(host.data(), e->ent2, sizeof(uint4) * (size_t)ncopy, hipMemcpyDeviceToHost, s));
+    HM_HIP(hipStreamSynchronize(s));
+    for (int64_t t = 0; t < ncopy; ++t) {
+        union { uint32_t u; float f; } cv; cv.u = host[(size_t)t].x;
+        d_out[t] = cv.f; i_out[t] = (int32_t)host[(size_t)t].y; j_out[t] = (int32_t)host[(size_t)t].z;
+    }
+    return HM_OK;
+}
+
+extern "C" int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, float* d_out_dev, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_row_vs_all: engine is NULL");
+    if (!d_out_dev || row < 0 || row >= e->n || n < 0 || n > e->n || !(c > 0.0f))
+        return hm_fail(e, HM_E_ARG, "hm_row_vs_all: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    if (n == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+                       row, n, sqrtf(c), e->sign_mode, d_out_dev);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_pair_distance(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, int64_t b, float c, float* out_dev,
+                                void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pair_distance: engine is NULL");
+    if (b < 0 || (b > 0 && (!I_dev || !J_dev || !out_dev)) || !(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pair_distance: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_pairdist_kernel, dim3((unsigned)((b + 127) / 128)), dim3(128), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+                       I_dev, J_dev, b, sqrtf(c), e->sign_mode, out_dev);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_midpoint_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev, int64_t b, float c,
+                                 float* out_dev, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_midpoint_batch: engine is NULL");
+    if (b < 0 || (b > 0 && (!I_dev || !J_dev || !W_dev || !out_dev))) return hm_fail(e, HM_E_ARG, "hm_midpoint_batch: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_midpoint_kernel, dim3((unsigned)((b + 63) / 64)), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+                       I_dev, J_dev, W_dev, b, c, e->sign_mode, out_dev);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, float c, float* X_dev, int64_t ld, int64_t new_row,
+                               void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_merge_append: engine is NULL");
+    if (!X_dev || ld < e->d1 || i < 0 || j < 0 || i >= e->n || j >= e->n || new_row < 0 || new_row >= e->max_rows)
+        return hm_fail(e, HM_E_ARG, "hm_merge_append: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    hipLaunchKernelGGL(hm_merge_append_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d, e->NG, i, j, w, c,
+                       e->sign_mode, X_dev, ld, new_row);
+    HM_HIP(hipGetLastError());
+    if (new_row < e->n) e->have_cut = false;
+    if (new_row + 1 > e->n) e->n = new_row + 1;
+    return HM_OK;
+}
+
+// ---- engine-independent entry points ----
+#define HM_HIP0(call)                                                                                 \
+    do {                                                                                              \
+        hipError_t _st = (call);                                                                      \
+        if (_st != hipSuccess)                                                                        \
+            return hm_fail(nullptr, (int)_st, std::string(#call) + ": " + hipGetErrorString(_st));    \
+    } while (0)
+
+extern "C" int hm_batch_distance(const float* X_dev, int64_t n1, const float* Y_dev, int64_t n2, int64_t ld_x, int64_t ld_y, int d1,
+                                 float c, int sign_mode, float* out_dev, void* stream)
+{
+    if (n1 < 0 || n2 < 0 || d1 < 2 || ld_x < d1 || ld_y < d1 || !(c > 0.0f)) return hm_fail(nullptr, HM_E_ARG, "hm_batch_distance: bad arguments");
+    if (n1 == 0 || n2 == 0) return HM_OK;
+    if (!X_dev || !Y_dev || !out_dev) return hm_fail(nullptr, HM_E_ARG, "hm_batch_distance: NULL pointer");
+    if (n1 > 2147483647LL / 1) return hm_fail(nullptr, HM_E_ARG, "hm_batch_distance: n1 too large");
+    for (int64_t i0 = 0; i0 < n1; i0 += 32768) {
+        const int64_t rows = std::min<int64_t>(32768, n1 - i0);
+        hipLaunchKernelGGL(hm_dense_kernel, dim3((unsigned)((n2 + 255) / 256), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                           X_dev + i0 * ld_x, rows, Y_dev, n2, ld_x, ld_y, d1, sqrtf(c), sign_mode, out_dev + i0 * n2);
+        HM_HIP0(hipGetLastError());
+    }
+    return HM_OK;
+}
+
+extern "C" int hm_rows_minkowski(const float* x_dev, const float* y_dev, int64_t b, int64_t ld, int d1, int sign_mode, float* out_dev,
+                                 void* stream)
+{
+    if (b < 0 || d1 < 2 || ld < d1) return hm_fail(nullptr, HM_E_ARG, "hm_rows_minkowski: bad arguments");
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rows_minkowski_kernel, dim3((unsigned)((b + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x_dev, y_dev, b,
+                       ld, d1, sign_mode, out_dev);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_rows_distance(const float* x_dev, const float* y_dev, int64_t b, int64_t ld, int d1, float c, int sign_mode,
+                                float* out_dev, void* stream)
+{
+    if (b < 0 || d1 < 2 || ld < d1 || !(c > 0.0f)) return hm_fail(nullptr, HM_E_ARG, "hm_rows_distance: bad arguments");
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rows_distance_kernel, dim3((unsigned)((b + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x_dev, y_dev, b,
+                       ld, d1, sqrtf(c), sign_mode, out_dev);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_rows_log_map(const float* x_dev, const float* y_dev, int64_t b, int64_t ld, int d1, int sign_mode, float* out_dev,
+                               int64_t ld_out, void* stream)
+{
+    if (b < 0 || d1 < 2 || ld < d1 || ld_out < d1) return hm_fail(nullptr, HM_E_ARG, "hm_rows_log_map: bad arguments");
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rows_log_map_kernel, dim3((unsigned)((b + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x_dev, y_dev, b,
+                       ld, d1, sign_mode, out_dev, ld_out);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_rows_exp_map(const float* x_dev, const float* v_dev, int64_t b, int64_t ld, int d1, float* out_dev, int64_t ld_out,
+                               void* stream)
+{
+    if (b < 0 || d1 < 2 || ld < d1 || ld_out < d1) return hm_fail(nullptr, HM_E_ARG, "hm_rows_exp_map: bad arguments");
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rows_exp_map_kernel, dim3((unsigned)((b + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x_dev, v_dev, b,
+                       ld, d1, out_dev, ld_out);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_rows_project(const float* x_dev, int64_t b, int64_t ld, int d1, float c, float* out_dev, int64_t ld_out,
+                               void* stream)
+{
+    if (b < 0 || d1 < 2 || ld < d1 || ld_out < d1) return hm_fail(nullptr, HM_E_ARG, "hm_rows_project: bad arguments");
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rows_project_kernel, dim3((unsigned)((b + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x_dev, b, ld, d1,
+                       c, out_dev, ld_out);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_last_scan_stats(const hm_engine* e, float* scan_ms, int64_t* pairs, int64_t* emitted, int32_t* passes)
+{
+    if (!e) return HM_E_ARG;
+    if (scan_ms) *scan_ms = e->last_scan_ms;
+    if (pairs) *pairs = e->last_pairs;
+    if (emitted) *emitted = e->last_emitted;
+    if (passes) *passes = e->last_passes;
+    return HM_OK;
+}

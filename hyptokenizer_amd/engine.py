@@ -1,0 +1,254 @@
+"""MergeEngine: the host-side handle of the gfx950 merge engine (libhypmerge.so).
+
+One engine per GPU.  The engine keeps a device-resident *scan image* of the live rows of the
+token-embedding table (``HyperbolicTokenizer.embeddings[:n]``, hyperbolic_merge.py:145-153) and
+serves the candidate searches and the midpoint update of the merge loop through the C ABI of
+``include/hypmerge.h``.  PyTorch provides device memory and the stream only.
+
+The product path has no CPU implementation: constructing a ``MergeEngine`` without a HIP device or
+without the built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SIGN_LORENTZ, SIGN_REFERENCE, HypMergeError, HypMergeUnavailable  # noqa: F401
+
+SIGN_MODES = {"reference": SIGN_REFERENCE, "lorentz": SIGN_LORENTZ}
+
+
+def sign_mode_id(sign_convention) -> int:
+    if isinstance(sign_convention, str):
+        try:
+            return SIGN_MODES[sign_convention]
+        except KeyError:
+            raise ValueError(f"sign_convention must be 'reference' or 'lorentz', got {sign_convention!r}") from None
+    if sign_convention in (0, 1):
+        return int(sign_convention)
+    raise ValueError(f"bad sign convention {sign_convention!r}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _np_ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+class MergeEngine:
+    """Handle of one ``hm_engine`` (include/hypmerge.h)."""
+
+    def __init__(self, max_rows: int, d1: int, sign_convention="reference", device: Optional[torch.device] = None):
+        self._L = _lib.load()
+        if not torch.cuda.is_available():
+            raise HypMergeUnavailable("MergeEngine needs a HIP device (torch.cuda.is_available() is False); "
+                                      "there is no CPU fallback")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise HypMergeUnavailable(f"MergeEngine needs a cuda(HIP) device, got {dev}")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.max_rows = int(max_rows)
+        self.d1 = int(d1)
+        self.sign_mode = sign_mode_id(sign_convention)
+        self._h = C.c_void_p(0)
+        _lib.check(self._L.hm_engine_create(C.byref(self._h), self.device.index, self.max_rows, self.d1,
+                                            self.sign_mode))
+
+    # ------------------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.hm_engine_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, st: int) -> None:
+        _lib.check(st, self._h)
+
+    def _check_table(self, table: torch.Tensor) -> torch.Tensor:
+        t = table.detach()
+        if t.device != self.device or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 \
+                or t.shape[1] != self.d1:
+            raise ValueError("table must be a float32 [rows, d1] tensor with unit inner stride on the engine's device")
+        return t
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def n(self) -> int:
+        return int(self._L.hm_rows(self._h))
+
+    def set_table(self, table: torch.Tensor, n_rows: int) -> None:
+        t = self._check_table(table)
+        self._chk(self._L.hm_set_table(self._h, _ptr(t), t.stride(0), int(n_rows), self._stream()))
+
+    def update_rows(self, table: torch.Tensor, row_begin: int, row_end: int) -> None:
+        t = self._check_table(table)
+        self._chk(self._L.hm_update_rows(self._h, _ptr(t), t.stride(0), int(row_begin), int(row_end), self._stream()))
+
+    # ------------------------------------------------------------------------------------------
+    def argmin(self, c: float, thr: float, row_begin: int = 0, row_end: int = -1) -> Optional[Tuple[float, int, int]]:
+        """Nearest pair (d, i, j) with d < thr in the reference's order, or None."""
+        d, i, j, f = C.c_float(0), C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
+        self._chk(self._L.hm_pairwise_argmin(self._h, float(c), float(thr), int(row_begin), int(row_end),
+                                             C.byref(d), C.byref(i), C.byref(j), C.byref(f), self._stream()))
+        if not f.value:
+            return None
+        return float(d.value), int(i.value), int(j.value)
+
+    def topk(self, c: float, thr: float, k: int, row_begin: int = 0, row_end: int = -1):
+        """k smallest candidates (d, i, j) in order and the exact candidate count."""
+        k = int(k)
+        d = np.empty(k, np.float32)
+        i = np.empty(k, np.int32)
+        j = np.empty(k, np.int32)
+        n_out, count = C.c_int64(0), C.c_int64(0)
+        self._chk(self._L.hm_pairwise_topk(self._h, float(c), float(thr), k, int(row_begin), int(row_end),
+                                           _np_ptr(d), _np_ptr(i), _np_ptr(j), C.byref(n_out), C.byref(count),
+                                           self._stream()))
+        m = int(n_out.value)
+        return d[:m], i[:m], j[:m], int(count.value)
+
+    def candidates(self, c: float, thr: float, row_begin: int = 0, row_end: int = -1, cap: int = 1 << 24):
+        """All candidates in row-major order: (i, j, d, total)."""
+        total = C.c_int64(0)
+        # first call sizes the arrays
+        self._chk(self._L.hm_pairwise_candidates(self._h, float(c), float(thr), int(row_begin), int(row_end), 0,
+                                                 None, None, None, C.byref(total), self._stream()))
+        m = min(int(total.value), int(cap))
+        i = np.empty(m, np.int32)
+        j = np.empty(m, np.int32)
+        d = np.empty(m, np.float32)
+        if m:
+            self._chk(self._L.hm_pairwise_candidates(self._h, float(c), float(thr), int(row_begin), int(row_end), m,
+                                                     _np_ptr(i), _np_ptr(j), _np_ptr(d), C.byref(total),
+                                                     self._stream()))
+            order = np.lexsort((j, i))
+            i, j, d = i[order], j[order], d[order]
+        return i, j, d, int(total.value)
+
+    # ------------------------------------------------------------------------------------------
+    def _idx(self, a: Sequence[int]) -> torch.Tensor:
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.int32).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=self.device)
+
+    def pair_distance(self, I, J, c: float) -> np.ndarray:
+        ti, tj = self._idx(I), self._idx(J)
+        out = torch.empty(ti.numel(), dtype=torch.float32, device=self.device)
+        self._chk(self._L.hm_pair_distance(self._h, _ptr(ti), _ptr(tj), ti.numel(), float(c), _ptr(out), self._stream()))
+        return out.cpu().numpy()
+
+    def midpoint(self, I, J, W, c: float) -> torch.Tensor:
+        ti, tj = self._idx(I), self._idx(J)
+        tw = torch.as_tensor(np.ascontiguousarray(W, dtype=np.float32), device=self.device)
+        out = torch.empty((ti.numel(), self.d1), dtype=torch.float32, device=self.device)
+        self._chk(self._L.hm_midpoint_batch(self._h, _ptr(ti), _ptr(tj), _ptr(tw), ti.numel(), float(c), _ptr(out),
+                                            self._stream()))
+        return out
+
+    def merge_append(self, i: int, j: int, w: float, c: float, table: torch.Tensor, new_row: int) -> None:
+        t = self._check_table(table)
+        if not (0 <= new_row < t.shape[0]):
+            raise ValueError("new_row outside the table")
+        self._chk(self._L.hm_merge_append(self._h, int(i), int(j), float(w), float(c), _ptr(t), t.stride(0),
+                                          int(new_row), self._stream()))
+
+    def row_vs_all(self, row: int, n: int, c: float) -> np.ndarray:
+        out = torch.empty(int(n), dtype=torch.float32, device=self.device)
+        self._chk(self._L.hm_row_vs_all(self._h, int(row), int(n), float(c), _ptr(out), self._stream()))
+        return out.cpu().numpy()
+
+    def scan_stats(self) -> dict:
+        ms, pairs, emitted, passes = C.c_float(0), C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        self._L.hm_last_scan_stats(self._h, C.byref(ms), C.byref(pairs), C.byref(emitted), C.byref(passes))
+        return {"scan_ms": float(ms.value), "pairs": int(pairs.value), "emitted": int(emitted.value),
+                "passes": int(passes.value)}
+
+
+# ----------------------------------------------------------------------------------------------
+# engine-independent device functions (embedding/lorentz_model.py surface)
+# ----------------------------------------------------------------------------------------------
+def _stream_of(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _require_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if not t.is_cuda:
+            raise HypMergeUnavailable("hyptokenizer_amd kernels run on a HIP device only (tensor is on "
+                                      f"{t.device}); there is no CPU fallback")
+
+
+def _rows2d(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    t = t.reshape(-1, t.shape[-1])
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def device_batch_distance(x: torch.Tensor, y: torch.Tensor, c: float, sign_mode: int) -> torch.Tensor:
+    _require_cuda(x, y)
+    L = _lib.load()
+    xx, yy = _rows2d(x), _rows2d(y)
+    out = torch.empty((xx.shape[0], yy.shape[0]), dtype=torch.float32, device=xx.device)
+    with torch.cuda.device(xx.device):
+        _lib.check(L.hm_batch_distance(_ptr(xx), xx.shape[0], _ptr(yy), yy.shape[0], xx.stride(0) if xx.shape[0] > 1 else xx.shape[1],
+                                       yy.stride(0) if yy.shape[0] > 1 else yy.shape[1], xx.shape[1], float(c), int(sign_mode),
+                                       _ptr(out), _stream_of(xx)))
+    return out
+
+
+def _broadcast_rows(x: torch.Tensor, y: torch.Tensor):
+    shape = torch.broadcast_shapes(x.shape, y.shape)
+    xb = x.expand(shape).reshape(-1, shape[-1]).contiguous().float()
+    yb = y.expand(shape).reshape(-1, shape[-1]).contiguous().float()
+    return xb, yb, shape
+
+
+def device_rows_op(op: str, x: torch.Tensor, y: Optional[torch.Tensor], c: float, sign_mode: int) -> torch.Tensor:
+    """Row-wise Lorentz primitive on broadcast operands; result shaped like the reference's."""
+    L = _lib.load()
+    if y is not None:
+        _require_cuda(x, y)
+        xb, yb, shape = _broadcast_rows(x.detach(), y.detach())
+    else:
+        _require_cuda(x)
+        shape = x.shape
+        xb = x.detach().reshape(-1, shape[-1]).contiguous().float()
+        yb = None
+    b, d1 = xb.shape
+    s = _stream_of(xb)
+    with torch.cuda.device(xb.device):
+        if op in ("minkowski", "distance"):
+            out = torch.empty(b, dtype=torch.float32, device=xb.device)
+            if op == "minkowski":
+                _lib.check(L.hm_rows_minkowski(_ptr(xb), _ptr(yb), b, d1, d1, int(sign_mode), _ptr(out), s))
+            else:
+                _lib.check(L.hm_rows_distance(_ptr(xb), _ptr(yb), b, d1, d1, float(c), int(sign_mode), _ptr(out), s))
+            return out.reshape(shape[:-1])
+        out = torch.empty((b, d1), dtype=torch.float32, device=xb.device)
+        if op == "log_map":
+            _lib.check(L.hm_rows_log_map(_ptr(xb), _ptr(yb), b, d1, d1, int(sign_mode), _ptr(out), d1, s))
+        elif op == "exp_map":
+            _lib.check(L.hm_rows_exp_map(_ptr(xb), _ptr(yb), b, d1, d1, _ptr(out), d1, s))
+        elif op == "project":
+            _lib.check(L.hm_rows_project(_ptr(xb), b, d1, d1, float(c), _ptr(out), d1, s))
+        else:
+            raise ValueError(op)
+    return out.reshape(shape)

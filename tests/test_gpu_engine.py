@@ -1,0 +1,146 @@
+"""GPU parity: the HIP engine through the C ABI vs the CPU oracle, bit for bit.
+
+Integer results (pair indices, counts) and -- because both sides implement the same canonical
+fp32 arithmetic -- distances and midpoint rows are compared for exact equality.
+The 1e-5 tolerance of the north star applies between the oracle and the torch reference
+(tests/test_oracle_golden.py); here any difference at all is a failure.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from hyptokenizer_amd.synthetic import lorentz_table  # noqa: E402
+
+MODES = {"reference": 0, "lorentz": 1}
+
+
+def _engine(X, mode, max_rows=None):
+    from hyptokenizer_amd.engine import MergeEngine
+    n, d1 = X.shape
+    max_rows = max_rows or n + 512
+    table = torch.zeros((max_rows, d1), dtype=torch.float32, device="cuda")
+    table[:n] = X.cuda()
+    eng = MergeEngine(max_rows, d1, mode)
+    eng.set_table(table, n)
+    return eng, table
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _quantile_thr(oracle, X, q_pairs, mode):
+    """threshold with about q_pairs candidates (lorentz mode)"""
+    n = X.shape[0]
+    D = oracle.batch_distance(X[:min(n, 600)], X[:min(n, 600)], 1.0, MODES[mode])
+    iu = np.triu_indices(D.shape[0], 1)
+    dd = np.sort(D[iu])
+    frac = q_pairs / (n * (n - 1) / 2)
+    return float(dd[min(len(dd) - 1, max(0, int(frac * len(dd))))])
+
+
+@pytest.mark.parametrize("n,d,scale", [(64, 10, 0.05), (257, 10, 0.05), (1000, 10, 0.05), (700, 50, 0.05),
+                                       (1500, 100, 0.05), (300, 5, 0.01), (999, 100, 0.5), (513, 37, 0.05)])
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_topk_matches_oracle(oracle, n, d, scale, mode):
+    X = lorentz_table(n, d, seed=42, scale=scale).numpy()
+    eng, _ = _engine(torch.from_numpy(X), mode)
+    thrs = [0.1, 1e-5, 10.0] if mode == "reference" else [
+        _quantile_thr(oracle, X, 50, mode), _quantile_thr(oracle, X, 5000, mode), _quantile_thr(oracle, X, 60000, mode), 1e-9]
+    for thr in thrs:
+        for k in (1, 100, 10000):
+            gd, gi, gj, gc = eng.topk(1.0, thr, k)
+            od, oi, oj, oc = oracle.pairwise_topk(X, n, 1.0, thr, MODES[mode], k)
+            assert gc == oc, (thr, k, gc, oc)
+            assert np.array_equal(gi, oi) and np.array_equal(gj, oj), (thr, k)
+            assert np.array_equal(_bits(gd), _bits(od)), (thr, k)
+
+
+@pytest.mark.parametrize("n,d,scale", [(257, 10, 0.05), (1000, 10, 0.05), (1500, 100, 0.05), (2100, 50, 0.05)])
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_argmin_matches_oracle(oracle, n, d, scale, mode):
+    X = lorentz_table(n, d, seed=43, scale=scale).numpy()
+    eng, _ = _engine(torch.from_numpy(X), mode)
+    for thr in (0.05, 0.3, 5.0, 1e-7):
+        got = eng.argmin(1.0, thr)
+        od, oi, oj, oc = oracle.pairwise_topk(X, n, 1.0, thr, MODES[mode], 1)
+        if oc == 0:
+            assert got is None
+        else:
+            assert got is not None
+            assert (got[1], got[2]) == (int(oi[0]), int(oj[0]))
+            assert _bits([got[0]])[0] == _bits(od)[0]
+    # curvature rescales the distance only
+    got = eng.argmin(2.5, 0.3)
+    od, oi, oj, oc = oracle.pairwise_topk(X, n, 2.5, 0.3, MODES[mode], 1)
+    assert (got is None) == (oc == 0)
+    if got:
+        assert (got[1], got[2]) == (int(oi[0]), int(oj[0])) and _bits([got[0]])[0] == _bits(od)[0]
+
+
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_row_ranges_partition(oracle, mode):
+    """row-sharded scans (multi-GPU decomposition) agree with the oracle on every range"""
+    n, d = 1300, 20
+    X = lorentz_table(n, d, seed=7, scale=0.05).numpy()
+    eng, _ = _engine(torch.from_numpy(X), mode)
+    thr = 0.25 if mode == "lorentz" else 0.1
+    total = 0
+    for (r0, r1) in [(0, 256), (256, 300), (300, 1024), (1024, 1300), (5, 6), (1299, 1300)]:
+        gd, gi, gj, gc = eng.topk(1.0, thr, 500, r0, r1)
+        od, oi, oj, oc = oracle.pairwise_topk(X, n, 1.0, thr, MODES[mode], 500, r0, r1)
+        assert gc == oc and np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(_bits(gd), _bits(od))
+        if (r0, r1) != (5, 6) and (r0, r1) != (1299, 1300):
+            total += gc
+        a = eng.argmin(1.0, thr, r0, r1)
+        assert (a is None) == (oc == 0)
+        if a:
+            assert (a[1], a[2]) == (int(oi[0]), int(oj[0]))
+    assert total == oracle.pairwise_count(X, n, 1.0, thr, MODES[mode])
+
+
+@pytest.mark.parametrize("d", [5, 10, 50, 100])
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_gathered_kernels_match_oracle(oracle, d, mode):
+    n = 400
+    X = lorentz_table(n, d, seed=11, scale=0.05).numpy()
+    X[17] = X[16]                      # identical rows: NaN tangent
+    eng, _ = _engine(torch.from_numpy(X), mode)
+    rng = np.random.default_rng(0)
+    I = rng.integers(0, n, 300).astype(np.int32)
+    J = rng.integers(0, n, 300).astype(np.int32)
+    I[:2], J[:2] = [16, 5], [17, 5]
+    W = rng.uniform(0.05, 0.95, 300).astype(np.float32)
+    for c in (1.0, 0.7):
+        assert np.array_equal(_bits(eng.pair_distance(I, J, c)), _bits(oracle.pair_distance(X, I, J, c, MODES[mode])))
+        g = eng.midpoint(I, J, W, c).cpu().numpy()
+        o = oracle.midpoint_batch(X, I, J, W, c, MODES[mode])
+        assert np.array_equal(_bits(g), _bits(o))
+        assert np.array_equal(_bits(eng.row_vs_all(3, n, c)), _bits(oracle.row_vs_all(X, n, 3, c, MODES[mode])))
+
+
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_merge_loop_sequence_bit_exact(oracle, mode):
+    """argmin -> fused midpoint/append, 60 steps: pair sequence and every new row identical"""
+    n0, d = 600, 10
+    X = lorentz_table(n0, d, seed=42, scale=0.05).numpy()
+    eng, table = _engine(torch.from_numpy(X), mode, max_rows=n0 + 100)
+    Xo = np.zeros((n0 + 100, d + 1), np.float32)
+    Xo[:n0] = X
+    n = n0
+    thr = 0.1
+    for step in range(60):
+        got = eng.argmin(1.0, thr)
+        od, oi, oj, oc = oracle.pairwise_topk(Xo, n, 1.0, thr, MODES[mode], 1)
+        assert (got is None) == (oc == 0)
+        if got is None:
+            break
+        assert (got[1], got[2]) == (int(oi[0]), int(oj[0])), step
+        w = np.float32(0.5 if step % 3 else 1.0 / 3.0)
+        eng.merge_append(got[1], got[2], float(w), 1.0, table, n)
+        Xo[n] = oracle.midpoint_batch(Xo, [got[1]], [got[2]], [w], 1.0, MODES[mode])[0]
+        assert np.array_equal(_bits(table[n].cpu().numpy()), _bits(Xo[n])), step
+        n += 1
+        assert eng.n == n
