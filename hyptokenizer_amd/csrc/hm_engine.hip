@@ -69,6 +69,7 @@ struct ScanArgs {
     uint32_t hist_lo;
     uint32_t hist_shift;
     int sample_stride;
+    const uint32_t* rmax2_bits; // largest squared row norm (float bits), see hm_rownorm_kernel
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -102,13 +103,38 @@ __device__ __forceinline__ float hm_img_spatial(const float* img, int RS, int64_
 }
 __device__ __forceinline__ float hm_img_time(const float* img, int RS, int64_t row) { return img[row * RS + RS - 4]; }
 
-// canonical u (argument of acosh) between two image rows: spatial fmaf chain in ascending k, then time
+// canonical u (argument of acosh) between two image rows: products rounded separately, summed in
+// torch's reduction order, then fl(fl(x0*y0) - S)  (DESIGN.md "Canonical arithmetic")
 __device__ __forceinline__ float hm_img_u(const float* img, int RS, int d, int64_t a, int64_t b, int sign_mode)
 {
-    float acc = 0.0f;
-    for (int s = 0; s < d; ++s) acc = __builtin_fmaf(hm_img_spatial(img, RS, a, s), hm_img_spatial(img, RS, b, s), acc);
-    const float m = __builtin_fmaf(hm_img_time(img, RS, a), hm_img_time(img, RS, b), -acc);
+    const float* ra = img + a * RS;
+    const float* rb = img + b * RS;
+    const float S = hm::torch_order_sum(
+        [&](int s) {
+            const int o = 4 * (s >> 2) + hm_pos_in_group(s & 3);
+            return ra[o] * rb[o];
+        },
+        d);
+    const float t = ra[RS - 4] * rb[RS - 4];
+    const float m = t - S;
     return sign_mode ? m : -m;
+}
+
+// largest squared row norm of the live rows (finite rows only), kept as float bits for atomicMax.
+// It scales the bound |u_fast - u_canonical| <= (d + 8) * 2^-23 * rmax2 used by the pair scan.
+__global__ void hm_rownorm_kernel(const float* __restrict__ img, int RS, int64_t row_begin, int64_t row_end,
+                                  uint32_t* __restrict__ rmax2_bits)
+{
+    const int64_t row = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float r2 = 0.0f;
+    if (row < row_end) {
+        const float* rr = img + row * RS;
+        for (int k = 0; k < RS; ++k) r2 = __builtin_fmaf(rr[k], rr[k], r2);
+    }
+    if (!(r2 < 3.0e38f)) r2 = 0.0f;                 // NaN / inf rows never form candidates
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) r2 = __builtin_fmaxf(r2, __shfl_xor(r2, off, 64));
+    if ((threadIdx.x & 63) == 0 && r2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(r2));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -156,6 +182,16 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
     const int i0w = rb * HM_ROWS_PER_BLOCK + wave * 64;          // first stationary row of this wave
     const bool wave_active = (i0w < p.row_end) && (i0w + 63 >= p.row_begin) && (i0w < p.n);
     const bool rows_full = (i0w >= p.row_begin) && (i0w + 63 < p.row_end);
+
+    // The MFMA result u_f (plain fmaf chain) and the canonical u_c (torch reduction order) are two
+    // roundings of the same exact form; |u_f - u_c| <= delta (gamma_n bound on both, |terms| <= rmax2).
+    const float rmax2 = hm::bitsf(*p.rmax2_bits);
+    const float delta = ((float)(RS + 4) * 1.1920929e-07f) * rmax2 * 1.0001f;
+    const float pre_f = p.u_hi + delta;              // candidate prefilter on u_f
+    const float lo_f = p.u_lo - delta;               // u_f below this: canonical d < thr for sure
+    const float zmax_f = 1.0f - delta;               // u_f at or below this: canonical u <= 1, d == 0
+    const bool cut_all = (p.cut_bits == 0xffffffffu);
+    const float cut_f = cut_all ? p.u_hi : hm::bitsf(p.cut_bits) + delta;
 
     uint32_t* lhist = nullptr;
     if (MODE == HM_MODE_HIST) {
@@ -255,16 +291,18 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
                         ext = SIGN ? __builtin_fmaxf(ext, acc[tm][tn][e]) : __builtin_fminf(ext, acc[tm][tn][e]);
             const float ext_u = SIGN ? -ext : ext;
 
-            float bound_f = p.u_hi;
-            uint32_t best_bits = 0xffffffffu, best_low = 0xffffffffu, bound_bits = hm::fbits(p.u_hi);
+            float bound_f = pre_f;
+            uint32_t best_bits = 0xffffffffu, best_low = 0xffffffffu;
             if (MODE == HM_MODE_ARGMIN) {
+                // running best key over everything published so far; an entry can only order before it
+                // if its u_f is within 2*delta (+ a few ulps of acosh wiggle) of the best u_f
                 const unsigned long long gk =
                     __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 best_bits = (uint32_t)(gk >> 32);
                 best_low = (uint32_t)gk;
                 if (best_bits != 0xffffffffu) {
-                    const uint32_t bb = best_bits + HM_TIE_SLACK + 1u;
-                    if (bb < bound_bits) { bound_bits = bb; bound_f = hm::bitsf(bb); }
+                    const float bb = hm::bitsf(best_bits + HM_TIE_SLACK) + 2.0f * delta;
+                    if (bb < bound_f) bound_f = bb;
                 }
             }
 
@@ -276,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
                 uint32_t n_emit = 0, n_sure = 0;
                 unsigned long long wkey = ~0ull;
                 float bnd = bound_f;
-                uint32_t cutb = p.cut_bits;
+                float cutv = cut_f;
                 uint32_t slot = 0;
                 auto visit = [&](const float w, const int tm, const int tn, const int e, const bool write) {
                     const float u = SIGN ? -w : w;
@@ -297,16 +335,19 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
                     }
                     bool emit;
                     uint32_t flag = 0;
+                    const bool zero = (u <= zmax_f) && (p.thr_pos != 0);     // certainly d == 0 < thr
                     if (MODE == HM_MODE_TOPK) {
-                        const bool sure = (up < p.u_lo) || (p.thr_pos && ub == 0x3f800000u);
+                        const bool sure = zero || (up < lo_f);
                         if (sure && !write) ++n_sure;
                         flag = sure ? 1u : 0u;
-                        emit = !sure || ub < cutb || (ub == cutb && i <= p.tie_imax);
+                        // zero-distance ties order by (i, j): a tie flood is cut by rows (tie_imax)
+                        emit = zero ? (i <= p.tie_imax) : (!sure || cut_all || up <= cutv);
                     } else {
+                        const uint32_t ubz = zero ? 0x3f7fffffu : ub;
                         const uint32_t low = ((uint32_t)i << 15) | ((uint32_t)j >> 2);
-                        emit = (ub != best_bits) || (low <= best_low);
+                        emit = !(zero && best_bits == 0x3f7fffffu) || (low <= best_low);
                         if (emit && !write) {
-                            const unsigned long long k = ((unsigned long long)ub << 32) | low;
+                            const unsigned long long k = ((unsigned long long)ubz << 32) | low;
                             wkey = k < wkey ? k : wkey;
                         }
                     }
@@ -331,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
                         if (lane == 63) base = atomicAdd(&p.ctr[0], total);
                         base = __shfl(base, 63, 64);
                         slot = base + incl - n_emit;
-                        asm volatile("" : "+v"(bnd), "+s"(cutb));      // opaque: no CSE with the count pass
+                        asm volatile("" : "+v"(bnd), "+v"(cutv));      // opaque: no CSE with the count pass
 #pragma unroll
                         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -376,9 +417,10 @@ __device__ __forceinline__ bool hm_key_less(uint32_t a0, uint32_t a1, uint32_t a
     return a2 < b2;
 }
 
-// one block: exact distance of every entry, threshold, lexicographic min of (dbits, i, j)
+// one block: canonical distance of every entry, threshold, lexicographic min of (dbits, i, j)
 __global__ __launch_bounds__(1024) void hm_post_argmin_kernel(const uint4* __restrict__ ent, const uint32_t* __restrict__ ctr,
-                                                              uint32_t cap, float sqrt_c, float thr, ArgminRec* out)
+                                                              uint32_t cap, const float* __restrict__ img, int RS, int d,
+                                                              int sign_mode, float sqrt_c, float thr, ArgminRec* out)
 {
     __shared__ uint32_t s0[1024], s1[1024], s2[1024];
     uint32_t m = ctr[0];
@@ -386,9 +428,9 @@ __global__ __launch_bounds__(1024) void hm_post_argmin_kernel(const uint4* __res
     uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
     for (uint32_t t = threadIdx.x; t < m; t += 1024) {
         const uint4 en = ent[t];
-        const float d = hm::acosh_c(hm::bitsf(en.x)) / sqrt_c;
-        if (d < thr) {
-            const uint32_t db = hm::fbits(d);
+        const float dd = hm::dist_from_u(hm_img_u(img, RS, d, en.y, en.z, sign_mode), sqrt_c);
+        if (dd < thr) {
+            const uint32_t db = hm::fbits(dd);
             if (hm_key_less(db, en.y, en.z, b0, b1, b2)) { b0 = db; b1 = en.y; b2 = en.z; }
         }
     }
@@ -409,26 +451,33 @@ __global__ __launch_bounds__(1024) void hm_post_argmin_kernel(const uint4* __res
     }
 }
 
-// entries {ubits, i, j, sure} -> {dbits | 0xffffffff, i, j, ubits}; counts valid entries
-__global__ void hm_post_distance_kernel(uint4* __restrict__ ent, const uint32_t* __restrict__ ctr, uint32_t cap, float sqrt_c,
-                                        float thr, uint32_t* __restrict__ counts /* [0] valid [1] valid & !sure */)
+// entries {bits(u_f'), i, j, sure} -> {dbits | 0xffffffff, i, j, bits(u_c')} with the canonical
+// distance; counts[0] valid, counts[1] valid & !sure, counts[3] sure & !valid (margin violated: must be 0)
+__global__ void hm_post_distance_kernel(uint4* __restrict__ ent, const uint32_t* __restrict__ ctr, uint32_t cap,
+                                        const float* __restrict__ img, int RS, int d, int sign_mode, float sqrt_c, float thr,
+                                        uint32_t* __restrict__ counts)
 {
     uint32_t m = ctr[0];
     if (m > cap) m = cap;
-    uint32_t nv = 0, nb = 0;
+    uint32_t nv = 0, nb = 0, bad = 0;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
-        uint4 en = ent[t];
-        const float d = hm::acosh_c(hm::bitsf(en.x)) / sqrt_c;
-        const bool valid = d < thr;
+        const uint4 en = ent[t];
+        const float uc = hm::clamp_min_one(hm_img_u(img, RS, d, en.y, en.z, sign_mode));
+        const float dd = hm::acosh_c(uc) / sqrt_c;
+        const bool valid = dd < thr;
         nv += valid ? 1u : 0u;
         nb += (valid && en.w == 0u) ? 1u : 0u;
-        ent[t] = make_uint4(valid ? hm::fbits(d) : 0xffffffffu, en.y, en.z, en.x);
+        bad += (!valid && en.w != 0u) ? 1u : 0u;
+        ent[t] = make_uint4(valid ? hm::fbits(dd) : 0xffffffffu, en.y, en.z, hm::fbits(uc));
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { nv += __shfl_xor(nv, off, 64); nb += __shfl_xor(nb, off, 64); }
+    for (int off = 32; off > 0; off >>= 1) {
+        nv += __shfl_xor(nv, off, 64); nb += __shfl_xor(nb, off, 64); bad += __shfl_xor(bad, off, 64);
+    }
     if ((threadIdx.x & 63) == 0) {
         if (nv) atomicAdd(&counts[0], nv);
         if (nb) atomicAdd(&counts[1], nb);
+        if (bad) atomicAdd(&counts[3], bad);
     }
 }
 
@@ -538,21 +587,17 @@ template <class GX, class GY, class PUT>
 __device__ __forceinline__ void hm_midpoint_core(int d, float w, float c, int sign_mode, GX gx, GY gy, PUT put, float* scratch)
 {
     // log_map (embedding/lorentz_model.py:96-119)
-    float acc = 0.0f;
-    for (int k = 1; k <= d; ++k) acc = __builtin_fmaf(gx(k), gy(k), acc);
-    const float mref = __builtin_fmaf(gx(0), gy(0), -acc);
+    const float S = hm::torch_order_sum([&](int s) { return gx(1 + s) * gy(1 + s); }, d);
+    const float t0 = gx(0) * gy(0);
+    const float mref = t0 - S;
     const float u = sign_mode ? mref : -mref;
     const float m = -u;
     const float a = hm::clamp_min_one(u);
     float coef = hm::acosh_c(a) / __builtin_sqrtf(a * a - 1.0f);
     if (coef == coef && coef > 1.0e4f) coef = 1.0e4f;
     // v = w * log ; exp_map (:73-93)
-    float n2 = 0.0f;
-    for (int k = 0; k <= d; ++k) {
-        const float v = (coef * (gy(k) + m * gx(k))) * w;
-        scratch[k] = v;
-        if (k >= 1) n2 = __builtin_fmaf(v, v, n2);
-    }
+    for (int k = 0; k <= d; ++k) scratch[k] = (coef * (gy(k) + m * gx(k))) * w;
+    float n2 = hm::torch_order_sum([&](int s) { return scratch[1 + s] * scratch[1 + s]; }, d);
     if (n2 == n2 && n2 < 1.0e-8f) n2 = 1.0e-8f;
     const float nn = __builtin_sqrtf(n2);
     const float ch = hm::cosh_c(nn), sh = hm::sinh_c(nn);
@@ -586,7 +631,8 @@ __global__ void hm_midpoint_kernel(const float* __restrict__ img, int RS, int d,
 
 // fused merge: midpoint of image rows (i, j) -> table row and image row `new_row`
 __global__ void hm_merge_append_kernel(float* __restrict__ img, int RS, int d, int NG, int32_t i, int32_t j, float w, float c,
-                                       int sign_mode, float* __restrict__ X, int64_t ld, int64_t new_row)
+                                       int sign_mode, float* __restrict__ X, int64_t ld, int64_t new_row,
+                                       uint32_t* __restrict__ rmax2_bits)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float scratch[HM_MAX_D1];
@@ -595,13 +641,16 @@ __global__ void hm_merge_append_kernel(float* __restrict__ img, int RS, int d, i
     auto gy = [&](int k) { return k == 0 ? hm_img_time(img, RS, rj) : hm_img_spatial(img, RS, rj, k - 1); };
     float* xr = X + new_row * ld;
     float* ir = img + new_row * RS;
+    float r2 = 0.0f;
     hm_midpoint_core(d, w, c, sign_mode, gx, gy,
                      [&](int k, float v) {
                          xr[k] = v;
+                         r2 = __builtin_fmaf(v, v, r2);
                          if (k == 0) ir[4 * NG] = v;
                          else ir[4 * ((k - 1) >> 2) + hm_pos_in_group((k - 1) & 3)] = v;
                      },
                      scratch);
+    if (r2 < 3.0e38f && r2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(r2));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -609,9 +658,9 @@ __global__ void hm_merge_append_kernel(float* __restrict__ img, int RS, int d, i
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float hm_rm_u(const float* x, const float* y, int d1, int sign_mode)
 {
-    float acc = 0.0f;
-    for (int k = 1; k < d1; ++k) acc = __builtin_fmaf(x[k], y[k], acc);
-    const float m = __builtin_fmaf(x[0], y[0], -acc);
+    const float S = hm::torch_order_sum([&](int s) { return x[1 + s] * y[1 + s]; }, d1 - 1);
+    const float t = x[0] * y[0];
+    const float m = t - S;
     return sign_mode ? m : -m;
 }
 
@@ -663,8 +712,7 @@ __global__ void hm_rows_exp_map_kernel(const float* __restrict__ x, const float*
     if (t >= b) return;
     const float* xr = x + t * ld;
     const float* vr = v + t * ld;
-    float n2 = 0.0f;
-    for (int k = 1; k < d1; ++k) n2 = __builtin_fmaf(vr[k], vr[k], n2);
+    float n2 = hm::torch_order_sum([&](int s) { return vr[1 + s] * vr[1 + s]; }, d1 - 1);
     if (n2 == n2 && n2 < 1.0e-8f) n2 = 1.0e-8f;
     const float nn = __builtin_sqrtf(n2);
     const float ch = hm::cosh_c(nn), sh = hm::sinh_c(nn);
@@ -691,7 +739,7 @@ __global__ void hm_rows_project_kernel(const float* __restrict__ x, int64_t b, i
 static thread_local std::string g_last_error;
 
 struct HostCtl {                 // pinned host mirror of small device results
-    uint32_t ctr[4];             // [0] emitted [1] valid [2] valid & !sure [3] compacted
+    uint32_t ctr[8];             // [0] emitted [1] valid [2] valid & !sure [3] compacted [4] margin violations
     unsigned long long ctr64[2]; // [0] sure count [1] argmin key
     ArgminRec rec;
     uint32_t hist[HM_DIGIT_BINS];
@@ -706,7 +754,8 @@ struct hm_engine {
     uint4* ent2 = nullptr;
     uint4* sorted = nullptr;
     uint32_t ent_cap = 0;
-    uint32_t* d_ctr = nullptr;            // 4 x u32
+    uint32_t* d_ctr = nullptr;            // 8 x u32
+    uint32_t* d_rmax2 = nullptr;          // float bits of the largest squared row norm
     unsigned long long* d_ctr64 = nullptr; // 2 x u64
     ArgminRec* d_rec = nullptr;
     uint32_t* d_hist = nullptr;           // HM_DIGIT_BINS
@@ -790,7 +839,9 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     HM_HIP(hipMalloc(&e->ent, sizeof(uint4) * (size_t)e->ent_cap));
     HM_HIP(hipMalloc(&e->ent2, sizeof(uint4) * (size_t)e->ent_cap));
     HM_HIP(hipMalloc(&e->sorted, sizeof(uint4) * (size_t)e->sorted_cap));
-    HM_HIP(hipMalloc(&e->d_ctr, sizeof(uint32_t) * 4));
+    HM_HIP(hipMalloc(&e->d_ctr, sizeof(uint32_t) * 8));
+    HM_HIP(hipMalloc(&e->d_rmax2, sizeof(uint32_t)));
+    HM_HIP(hipMemset(e->d_rmax2, 0, sizeof(uint32_t)));
     HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 2));
     HM_HIP(hipMalloc(&e->d_rec, sizeof(ArgminRec)));
     HM_HIP(hipMalloc(&e->d_hist, sizeof(uint32_t) * HM_DIGIT_BINS));
@@ -806,7 +857,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
 {
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
-    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist};
+    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2};
     for (void* q : dev_ptrs) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);
     if (e->h_sorted) (void)hipHostFree(e->h_sorted);
@@ -825,6 +876,8 @@ static int hm_build_rows(hm_engine* e, const float* X, int64_t ld, int64_t r0, i
     int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(hm_build_image_kernel, dim3(blocks), dim3(256), 0, s, X, ld, e->d, e->NG, e->img, r0, r1);
     HM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(hm_rownorm_kernel, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, s, e->img, e->RS, r0, r1, e->d_rmax2);
+    HM_HIP(hipGetLastError());
     return HM_OK;
 }
 
@@ -837,6 +890,7 @@ extern "C" int hm_set_table(hm_engine* e, const float* X_dev, int64_t ld, int64_
     HM_HIP(hipSetDevice(e->device));
     if (e->n > n_rows)   // rows that are no longer live must read as zeros (never candidates: masked)
         HM_HIP(hipMemsetAsync(e->img + n_rows * e->RS, 0, sizeof(float) * (size_t)(e->n - n_rows) * e->RS, s));
+    HM_HIP(hipMemsetAsync(e->d_rmax2, 0, sizeof(uint32_t), s));
     int rc = hm_build_rows(e, X_dev, ld, 0, n_rows, s);
     if (rc) return rc;
     e->n = n_rows;
@@ -964,6 +1018,7 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     a.ctr64 = e->d_ctr64;
     a.hist = e->d_hist;
     a.sample_stride = 1;
+    a.rmax2_bits = e->d_rmax2;
     const int nrb = (int)((row_end - 1) / HM_ROWS_PER_BLOCK) - a.rb_first + 1;
     // column tiles per block: keep >= ~2048 blocks in flight for large tables, amortise the
     // stationary-row load for small ones
@@ -996,15 +1051,18 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
     if (b.none || e->n < 2 || !hm_prepare_scan(e, b, row_begin, row_end, a, grid)) return HM_OK;
     const float sqrt_c = sqrtf(c);
     for (int pass = 0; pass < 2; ++pass) {
-        HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 4, s));
-        HM_HIP(hipMemsetAsync(e->d_ctr64, 0xff, sizeof(unsigned long long) * 2, s));
+        HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
+        // pass 1 (after an overflow) keeps the final running key of pass 0: every wave then starts
+        // with the tight bound and only the band around the minimum is emitted
+        if (pass == 0) HM_HIP(hipMemsetAsync(e->d_ctr64, 0xff, sizeof(unsigned long long) * 2, s));
         HM_HIP(hipEventRecord(e->ev0, s));
         HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s));
         HM_HIP(hipEventRecord(e->ev1, s));
-        hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(1), dim3(1024), 0, s, e->ent, e->d_ctr, e->ent_cap, sqrt_c, thr, e->d_rec);
+        hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(1), dim3(1024), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img, e->RS, e->d,
+                           e->sign_mode, sqrt_c, thr, e->d_rec);
         HM_HIP(hipGetLastError());
         HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
-        HM_HIP(hipMemcpyAsync(e->h->ctr, e->d_ctr, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipMemcpyAsync(e->h->ctr, e->d_ctr, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, s));
         HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_ctr64, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, s));
         HM_HIP(hipStreamSynchronize(s));
         float ms = 0.f;
@@ -1014,13 +1072,8 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
         e->last_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
         e->last_emitted = e->h->ctr[0];
         if (e->h->ctr[0] <= e->ent_cap) break;
-        // overflow: the running best key is exact (every surviving wave published it); rerun with
-        // the final bound as a static start so that only the tie band is emitted
+        // overflow: the running key is the exact minimum over all published waves; rerun bounded by it
         if (pass == 1) return hm_fail(e, HM_E_CAPACITY, "hm_pairwise_argmin: emission buffer overflow on the bounded pass");
-        const uint32_t best_bits = (uint32_t)(e->h->ctr64[1] >> 32);
-        uint32_t bb = best_bits + HM_TIE_SLACK + 1u;
-        union { uint32_t u; float f; } cv; cv.u = bb;
-        if (cv.f < a.u_hi) a.u_hi = cv.f;
     }
     if (e->h->rec.found) {
         union { uint32_t u; float f; } cv; cv.u = e->h->rec.dbits;
@@ -1161,15 +1214,15 @@ static int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row
     for (int attempt = 0; attempt < 8; ++attempt) {
         a.cut_bits = cut_bits;
         a.tie_imax = tie_imax;
-        HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 4, s));
+        HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
         HM_HIP(hipMemsetAsync(e->d_ctr64, 0, sizeof(unsigned long long) * 2, s));
         HM_HIP(hipEventRecord(e->ev0, s));
         HM_HIP(hm_launch_scan(e, HM_MODE_TOPK, a, grid, s));
         HM_HIP(hipEventRecord(e->ev1, s));
-        hipLaunchKernelGGL(hm_post_distance_kernel, dim3(512), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, sqrt_c, thr,
-                           e->d_ctr + 1);
+        hipLaunchKernelGGL(hm_post_distance_kernel, dim3(512), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img, e->RS, e->d,
+                           e->sign_mode, sqrt_c, thr, e->d_ctr + 1);
         HM_HIP(hipGetLastError());
-        HM_HIP(hipMemcpyAsync(e->h->ctr, e->d_ctr, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipMemcpyAsync(e->h->ctr, e->d_ctr, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, s));
         HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_ctr64, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, s));
         HM_HIP(hipStreamSynchronize(s));
         float ms = 0.f;
@@ -1178,6 +1231,9 @@ static int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row
         e->last_passes += 1;
         e->last_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
         e->last_emitted = e->h->ctr[0];
+        if (e->h->ctr[4] != 0)
+            return hm_fail(e, HM_E_STATE, "pair scan: prefilter margin violated (an entry classified as surely below the "
+                                          "threshold is not); table holds non-finite rows other than all-NaN rows?");
         const uint64_t emitted = e->h->ctr[0];
         const bool overflow = emitted > e->ent_cap;
         const int64_t total = (int64_t)e->h->ctr64[0] + (int64_t)e->h->ctr[2];   // sure + valid borderline
@@ -1335,7 +1391,7 @@ extern "C" int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, floa
         return hm_fail(e, HM_E_ARG, "hm_merge_append: bad arguments");
     HM_HIP(hipSetDevice(e->device));
     hipLaunchKernelGGL(hm_merge_append_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d, e->NG, i, j, w, c,
-                       e->sign_mode, X_dev, ld, new_row);
+                       e->sign_mode, X_dev, ld, new_row, e->d_rmax2);
     HM_HIP(hipGetLastError());
     if (new_row < e->n) e->have_cut = false;
     if (new_row + 1 > e->n) e->n = new_row + 1;

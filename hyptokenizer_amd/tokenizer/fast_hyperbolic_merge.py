@@ -1,0 +1,278 @@
+"""FastHyperbolicTokenizer on the MI355X merge engine.
+
+Class surface of the reference's ``tokenizer/fast_hyperbolic_merge.py``: ``MergeCandidate``,
+``AdaptiveMergeCache``, ``FastHyperbolicTokenizer`` with the same constructor kwargs, attributes,
+cache stepping and threshold dynamics.  The reference's recompute branch -- ``batch_distance`` over
+the whole table, a Python loop over ``nonzero()``, a full sort, and the FAISS/HNSW sampled search
+above 10 000 tokens (``:274-374``) -- is replaced by ONE exact GPU search that returns the ordered
+``cache_size`` best candidates and the exact candidate count (``MergeEngine.topk``).
+
+Cache semantics kept exactly: a refresh stores ``S[:max_size]`` WITHOUT
+removing ``S[0]``, returns ``S``; later steps pop 100 entries and merge the first of them; cached
+entries are never invalidated.  Only ``candidates[0]``, ``len(candidates)`` and emptiness are ever
+consumed by the loop (``:511-549``).
+"""
+from __future__ import annotations
+
+import logging
+import random
+import time
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .hyperbolic_merge import HyperbolicTokenizer
+
+FAISS_AVAILABLE = False     # replaced entirely by the exact GPU search
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass
+class MergeCandidate:
+    """``(distance, token_i, token_j)``; ordering by distance only (reference ``:52-60``)."""
+    distance: float
+    token_i: int
+    token_j: int
+
+    def __lt__(self, other):
+        return self.distance < other.distance
+
+
+class CandidateList(Sequence):
+    """The sorted candidate list ``S`` of one refresh.
+
+    ``len()`` is the exact number of candidates; only the first ``cache_size`` entries (everything
+    the reference's cache ever keeps, ``:91-95``) are stored.  Indexing past them raises
+    ``IndexError``."""
+
+    def __init__(self, d: np.ndarray, i: np.ndarray, j: np.ndarray, total: int):
+        self._d, self._i, self._j = d, i, j
+        self._total = int(total)
+
+    def __len__(self) -> int:
+        return self._total
+
+    @property
+    def stored(self) -> int:
+        return len(self._d)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            idx = range(*k.indices(self.stored))
+            return [self[q] for q in idx]
+        if k < 0:
+            k += self._total
+        if not 0 <= k < self.stored:
+            raise IndexError("only the first cache_size candidates of a refresh are materialised")
+        return MergeCandidate(float(self._d[k]), int(self._i[k]), int(self._j[k]))
+
+    def __iter__(self):
+        for k in range(self.stored):
+            yield self[k]
+
+    def __bool__(self) -> bool:
+        return self._total > 0
+
+
+class AdaptiveMergeCache:
+    """Sorted candidate cache (reference ``:63-133``): ``add_batch`` = concat + stable sort +
+    truncate to ``max_size``; ``get_best(n)`` pops the first n.  ``hit_count`` only records pairs
+    that were actually served (the reference also stores a zero for every candidate ever seen,
+    which has no effect on ``get_stats``)."""
+
+    def __init__(self, max_size: int = 10000):
+        self.max_size = max_size
+        self.candidates: List[MergeCandidate] = []
+        self.hit_count: Dict[Tuple[int, int], int] = {}
+        self.miss_count: int = 0
+        self._hits = 0                      # running sum(hit_count.values())
+
+    def add_batch(self, new_candidates) -> None:
+        if isinstance(new_candidates, CandidateList):
+            fresh = new_candidates[: self.max_size]
+        else:
+            fresh = list(new_candidates)
+        merged = self.candidates + fresh
+        merged.sort()                       # stable, by distance only
+        self.candidates = merged[: self.max_size]
+
+    def get_best(self, n: int = 1) -> List[MergeCandidate]:
+        if not self.candidates:
+            self.miss_count += 1
+            return []
+        best = self.candidates[:n]
+        for cand in best:
+            key = (cand.token_i, cand.token_j)
+            self.hit_count[key] = self.hit_count.get(key, 0) + 1
+        self._hits += len(best)
+        self.candidates = self.candidates[n:]
+        return best
+
+    def get_stats(self) -> Dict[str, Any]:
+        hits = self._hits
+        return {
+            "size": len(self.candidates),
+            "max_size": self.max_size,
+            "hit_count": hits,
+            "miss_count": self.miss_count,
+            "hit_ratio": hits / (hits + self.miss_count + 1e-10),
+        }
+
+
+class FastHyperbolicTokenizer(HyperbolicTokenizer):
+    """Merge loop with a candidate cache; one exact GPU search per ~101 steps."""
+
+    def __init__(
+        self,
+        vocab: List[str],
+        embeddings: torch.nn.Parameter,
+        curvature: float = 1.0,
+        merge_threshold: float = 0.1,
+        lr: float = 1e-3,
+        device: Optional[torch.device] = None,
+        max_vocab_size: int = 100000,
+        use_approximate_search: bool = True,
+        cache_size: int = 10000,
+        rebuild_frequency: int = 100,
+        hnsw_m: int = 32,
+        hnsw_ef_construction: int = 200,
+        hnsw_ef_search: int = 100,
+        *,
+        sign_convention: str = "reference",
+        engine=None,
+    ):
+        super().__init__(vocab=vocab, embeddings=embeddings, curvature=curvature, merge_threshold=merge_threshold,
+                         lr=lr, device=device, max_vocab_size=max_vocab_size,
+                         use_approximate_search=use_approximate_search, sign_convention=sign_convention,
+                         engine=engine)
+        self.index = None
+        self.index_outdated = True
+        self.cache = AdaptiveMergeCache(max_size=cache_size)
+        self.rebuild_frequency = rebuild_frequency
+        self.merges_since_rebuild = 0
+        # HNSW knobs are kept as attributes for compatibility; no index exists on this path
+        self.hnsw_m = hnsw_m
+        self.hnsw_ef_construction = hnsw_ef_construction
+        self.hnsw_ef_search = hnsw_ef_search
+
+    def _build_faiss_index(self) -> None:
+        """Reference ``:195-240``.  The HNSW index is replaced by the exact search: nothing to build."""
+        self.use_approximate_search = False
+        self.index = None
+
+    def _find_merge_candidates(self) -> List[Tuple[int, int, float]]:
+        """Base-class tuple format (reference ``:242-251``); holds the materialised candidates."""
+        found = self._find_merge_candidates_fast()
+        return [(c.token_i, c.token_j, c.distance) for c in found]
+
+    def _find_merge_candidates_fast(self):
+        """Cache pop, else one exact search + cache refill (reference ``:253-376``)."""
+        cached = self.cache.get_best(100)
+        if cached:
+            return cached
+        eng = self._get_engine()
+        d, i, j, total = eng.topk(self.curvature, self._search_threshold(), self.cache.max_size)
+        found = CandidateList(d, i, j, total)
+        self.cache.add_batch(found)
+        return found
+
+    def _merge_tokens(self, i: int, j: int) -> None:
+        super()._merge_tokens(i, j)
+        self.merges_since_rebuild += 1
+        if self.merges_since_rebuild >= self.rebuild_frequency:
+            self.index_outdated = True
+
+    def _evaluate_merge_quality_batch(self, candidates: List[MergeCandidate], text_sample: List[str]) -> List[float]:
+        """Reference ``:394-431`` (never called by the loop): frequency x length balance / distance."""
+        scores = []
+        for cand in candidates[:100]:
+            a, b = self.vocab[cand.token_i], self.vocab[cand.token_j]
+            freq = sum(1 for text in text_sample if a + b in text)
+            balance = 1.0 / (1.0 + abs(len(a) - len(b)))
+            scores.append(freq * balance / (cand.distance + 1e-6))
+        return scores
+
+    def _compute_distance_statistics(self, sample_size: int = 1000) -> Dict[str, float]:
+        """Distances of ``random.sample(range(n), 2)`` pairs (reference ``:433-465``).  The Python
+        RNG is consumed in the reference's order; the distances are one batched kernel call."""
+        n = self.current_vocab_size
+        count = min(sample_size, n * (n - 1) // 2)
+        ii, jj = [], []
+        for _ in range(count):
+            a, b = random.sample(range(n), 2)
+            ii.append(a)
+            jj.append(b)
+        if not ii:
+            return {"min": 0.0, "max": 0.0, "mean": 0.0, "std": 0.0}
+        dists = [float(v) for v in self._get_engine().pair_distance(ii, jj, self.curvature)]
+        return {"min": min(dists), "max": max(dists), "mean": np.mean(dists), "std": np.std(dists)}
+
+    def optimize_merges(self, steps: int = 10000, log_every: int = 1000, text_sample: Optional[List[str]] = None,
+                        adaptive_threshold: bool = True) -> None:
+        """Reference ``:467-576`` step for step (threshold rewrites, statistics calls and their RNG
+        consumption, empty-step handling, x1.1 every 1000 steps)."""
+        from tqdm import tqdm
+
+        bar = tqdm(range(steps), desc="Optimizing merges")
+        empty_steps = 0
+        stats = {"step": [], "vocab_size": [], "min_dist": [], "max_dist": [], "mean_dist": [], "num_candidates": []}
+
+        if adaptive_threshold:
+            ds = self._compute_distance_statistics()
+            logger.info(f"Initial distance statistics: min={ds['min']:.6f}, max={ds['max']:.6f}, mean={ds['mean']:.6f}")
+            if ds["max"] < 1e-6:
+                logger.warning("WARNING: Maximum distance is near zero! This will prevent finding merge candidates.")
+                logger.warning("Consider reinitializing embeddings with a larger initialization scale.")
+                self.merge_threshold = 1e-5
+                logger.info(f"Auto-adjusting merge threshold to {self.merge_threshold:.6f}")
+            if ds["max"] > 0 and self.merge_threshold > ds["max"]:
+                self.merge_threshold = min(self.merge_threshold, ds["mean"] * 1.5)
+                logger.info(f"Adjusted initial merge threshold to {self.merge_threshold:.6f}")
+
+        for step in bar:
+            t0 = time.time()
+            found = self._find_merge_candidates_fast()
+
+            if step % log_every == 0 or not found:
+                ds = self._compute_distance_statistics()
+                stats["step"].append(step)
+                stats["vocab_size"].append(self.current_vocab_size)
+                stats["min_dist"].append(ds["min"])
+                stats["max_dist"].append(ds["max"])
+                stats["mean_dist"].append(ds["mean"])
+                stats["num_candidates"].append(len(found))
+                logger.info(f"\nStep {step}: vocab_size={self.current_vocab_size}")
+                logger.info(f"  Distance stats: min={ds['min']:.6f}, max={ds['max']:.6f}, mean={ds['mean']:.6f}")
+                logger.info(f"  Merge candidates: {len(found)}")
+                logger.info(f"  Merge threshold: {self.merge_threshold:.6f}")
+
+            if not found:
+                empty_steps += 1
+                if empty_steps > 5 and adaptive_threshold:
+                    self.merge_threshold *= 1.5
+                    logger.info(f"No candidates found. Increasing threshold to {self.merge_threshold:.6f}")
+                    empty_steps = 0
+                    continue
+                elif empty_steps > 10:
+                    logger.info(f"No more merge candidates found after {step} steps")
+                    break
+                continue
+            empty_steps = 0
+
+            best = found[0]
+            self._merge_tokens(best.token_i, best.token_j)
+
+            elapsed = time.time() - t0
+            cs = self.cache.get_stats()
+            bar.set_postfix({"vocab_size": self.current_vocab_size, "best_dist": best.distance,
+                             "threshold": self.merge_threshold, "time": f"{elapsed:.2f}s",
+                             "hit_ratio": f"{cs['hit_ratio']:.2f}"})
+            if (step + 1) % log_every == 0:
+                logger.info(f"Step {step+1}: merged '{self.vocab[best.token_i]}' + "
+                            f"'{self.vocab[best.token_j]}' -> '{self.vocab[-1]}' (dist: {best.distance:.4f})")
+            if adaptive_threshold and step > 0 and step % 1000 == 0:
+                self.merge_threshold *= 1.1
+        self.last_run_stats = stats     # the reference builds this dict and drops it (:484)

@@ -1,0 +1,281 @@
+"""HyperbolicTokenizer on the MI355X merge engine.
+
+Same class surface as the reference's ``tokenizer/hyperbolic_merge.py`` (constructor kwargs,
+attributes, method names, save/load files); the candidate search and the midpoint update run on the
+GPU through ``hyptokenizer_amd.engine.MergeEngine`` instead of ``batch_distance`` + Python loops.
+What a step computes is unchanged:
+
+* candidates = pairs ``i < j`` with ``d(i, j) < merge_threshold`` (reference ``:247-269``),
+* the merged pair is the first of the list sorted by distance, ties in row-major order (``:378``),
+* the new row is ``project(exp_map(x_i, w_j * log_map(x_i, x_j)))`` appended at row ``n``
+  (``:326-351``); rows are never removed.
+
+Additive keyword-only arguments: ``sign_convention`` ("reference" = arithmetic as shipped, the
+default; "lorentz" = sign-corrected) and ``engine`` (an object with the
+``MergeEngine`` interface; tests inject an oracle-backed double, the product never does).
+The FAISS pre-filter of the reference (``:203-244``, ``:593-625``) is replaced by the exact GPU
+search and never used: ``FAISS_AVAILABLE`` is always False here.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from ..embedding.lorentz_model import batch_distance, distance
+from ..engine import HypMergeUnavailable, MergeEngine, sign_mode_id
+
+logger = logging.getLogger(__name__)
+
+FAISS_AVAILABLE = False            # the HNSW / Flat index path is replaced by the exact GPU search
+TORCH_COMPILE_AVAILABLE = hasattr(torch, "compile")
+USING_COMPILED = False             # no tracing compiler on this path: the kernels are hand-written
+distance_compiled = distance
+batch_distance_compiled = batch_distance
+
+
+def threshold_for_fp32_compare(thr: float) -> float:
+    """``tensor_fp32 < python_float`` compares in fp32 (reference ``:262``): nearest float32."""
+    return float(np.float32(thr))
+
+
+def threshold_for_double_compare(thr: float) -> float:
+    """``float(d32) < thr`` in double (reference ``:288``, n <= 100 branch) equals the fp32 test
+    ``d32 < t`` with ``t`` the smallest float32 >= thr."""
+    t = np.float32(thr)
+    if float(t) < thr:
+        t = np.nextafter(t, np.float32(np.inf))
+    return float(t)
+
+
+class HyperbolicTokenizer:
+    """Tokenizer whose merges are chosen by hyperbolic distance between token embeddings."""
+
+    def __init__(
+        self,
+        vocab: List[str],
+        embeddings: torch.nn.Parameter,
+        curvature: float = 1.0,
+        merge_threshold: float = 0.1,
+        lr: float = 1e-3,
+        device: Optional[torch.device] = None,
+        max_vocab_size: int = 100000,
+        use_approximate_search: bool = True,
+        *,
+        sign_convention: str = "reference",
+        engine=None,
+    ):
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.device = torch.device(device)
+        self.vocab = list(vocab)
+        self.current_vocab_size = len(vocab)
+        self.max_vocab_size = max_vocab_size
+        self.curvature = curvature
+        self.merge_threshold = merge_threshold
+        self.lr = lr
+        self.use_approximate_search = bool(use_approximate_search and FAISS_AVAILABLE)
+        self.sign_convention = sign_convention
+        sign_mode_id(sign_convention)
+
+        width = embeddings.size(1)
+        table = torch.zeros((max_vocab_size, width), dtype=embeddings.dtype, device=self.device)
+        table[: self.current_vocab_size] = embeddings.detach().to(self.device)
+        self.embeddings = torch.nn.Parameter(table)
+
+        self.token2idx = {tok: k for k, tok in enumerate(self.vocab)}
+        self.merge_history: List[Tuple[str, str, str]] = []
+        self.index = None
+
+        self._engine = engine
+        self._engine_key = None       # (table identity, version, rows) the engine image was built from
+
+    # ------------------------------------------------------------------------------------------
+    # engine plumbing
+    # ------------------------------------------------------------------------------------------
+    def _get_engine(self):
+        """Engine whose image holds rows ``[0, current_vocab_size)`` of ``self.embeddings``."""
+        if self._engine is None:
+            if self.device.type != "cuda":
+                raise HypMergeUnavailable(
+                    "HyperbolicTokenizer's candidate search and merge run on a HIP device only "
+                    f"(device={self.device}); there is no CPU fallback")
+            self._engine = MergeEngine(self.max_vocab_size, self.embeddings.size(1), self.sign_convention,
+                                       self.device)
+        key = self._table_key()
+        if key != self._engine_key:
+            self._engine.set_table(self.embeddings.data, self.current_vocab_size)
+            self._engine_key = key
+        return self._engine
+
+    def _table_key(self):
+        # in-place edits of the Parameter bump _version; edits through ``.data`` do not -- call
+        # refresh_engine() after those
+        return (self.embeddings.data_ptr(), self.embeddings._version, self.current_vocab_size)
+
+    def refresh_engine(self) -> None:
+        """Force the engine to re-read the table (after editing ``embeddings.data`` by hand)."""
+        self._engine_key = None
+
+    def _search_threshold(self) -> float:
+        n = self.current_vocab_size
+        return threshold_for_fp32_compare(self.merge_threshold) if n > 100 \
+            else threshold_for_double_compare(self.merge_threshold)
+
+    # ------------------------------------------------------------------------------------------
+    # reference surface
+    # ------------------------------------------------------------------------------------------
+    def _compute_pairwise_distances(self) -> torch.Tensor:
+        """Full ``[n, n]`` distance matrix (reference ``:166-190``)."""
+        n = self.current_vocab_size
+        live = self.embeddings.data[:n]
+        return batch_distance(live, live, self.curvature, sign_convention=self.sign_convention)
+
+    def _find_merge_candidates(self) -> List[Tuple[int, int, float]]:
+        """Every ``(i, j, distance)`` with ``i < j`` and ``distance < merge_threshold``, row-major
+        (reference ``:192-291``)."""
+        eng = self._get_engine()
+        i, j, d, _total = eng.candidates(self.curvature, self._search_threshold())
+        return [(int(a), int(b), float(x)) for a, b, x in zip(i.tolist(), j.tolist(), d.tolist())]
+
+    def _best_candidate(self) -> Optional[Tuple[int, int, float]]:
+        """``sorted(candidates, key=distance)[0]`` without building the list."""
+        hit = self._get_engine().argmin(self.curvature, self._search_threshold())
+        if hit is None:
+            return None
+        d, i, j = hit
+        return i, j, d
+
+    def _is_valid_merge(self, token_i: str, token_j: str) -> bool:
+        return True               # reference ``:293-307``
+
+    def _merge_weight(self, i: int, j: int) -> float:
+        li, lj = len(self.vocab[i]), len(self.vocab[j])
+        return lj / (li + lj)
+
+    def _merge_tokens(self, i: int, j: int) -> None:
+        """Append the merged token and its embedding (reference ``:309-355``)."""
+        left, right = self.vocab[i], self.vocab[j]
+        merged = left + right
+        n = self.current_vocab_size
+        if n >= self.max_vocab_size:
+            raise ValueError(f"Maximum vocabulary size {self.max_vocab_size} reached. Cannot merge more tokens.")
+        eng = self._get_engine()
+        eng.merge_append(i, j, self._merge_weight(i, j), self.curvature, self.embeddings.data, n)
+        self.vocab.append(merged)
+        self.token2idx[merged] = n
+        self.current_vocab_size = n + 1
+        self._engine_key = self._table_key()      # the image already holds row n
+        self.merge_history.append((left, right, merged))
+
+    def optimize_merges(self, steps: int = 10000, log_every: int = 1000, parallel_eval: bool = True,
+                        sample_ratio: float = 1.0) -> None:
+        """Greedy merge loop (reference ``:357-412``).  ``parallel_eval`` and ``sample_ratio`` never
+        change which pair is merged in the reference (``:381-393``, ``:553-591``) and are accepted
+        for compatibility."""
+        bar = tqdm(range(steps), desc="Optimizing merges")
+        for step in bar:
+            best = self._best_candidate()
+            if best is None:
+                logger.info("No more merge candidates found. Stopping.")
+                break
+            i, j, dist = best
+            self._merge_tokens(i, j)
+            if (step + 1) % log_every == 0:
+                logger.info(f"Step {step+1}: merged '{self.vocab[i]}' + '{self.vocab[j]}' -> "
+                            f"'{self.vocab[-1]}' (dist: {dist:.4f})")
+                logger.info(f"Vocabulary size: {len(self.vocab)}")
+            bar.set_postfix({"vocab_size": len(self.vocab), "best_dist": dist, "threshold": self.merge_threshold})
+
+    def _evaluate_candidates_parallel(self, candidates: List[Tuple[int, int, float]]) -> Tuple[int, int, float]:
+        """Reference ``:553-591``: simulate the merges, then return the first candidate unchanged."""
+        if candidates:
+            eng = self._get_engine()
+            ii = [c[0] for c in candidates]
+            jj = [c[1] for c in candidates]
+            eng.midpoint(ii, jj, [self._merge_weight(a, b) for a, b in zip(ii, jj)], self.curvature)
+        return candidates[0]
+
+    def _init_faiss_index(self) -> None:     # reference ``:593-605``; replaced by the GPU search
+        self.index = None
+
+    def _update_faiss_index(self) -> None:   # reference ``:607-625``; replaced by the GPU search
+        return None
+
+    # ------------------------------------------------------------------------------------------
+    # inference (host Python, same semantics as the reference ``:414-471``)
+    # ------------------------------------------------------------------------------------------
+    def tokenize(self, text: str) -> List[str]:
+        if not hasattr(self, "_merge_rules"):
+            self._merge_rules = {(a, b): ab for a, b, ab in self.merge_history}
+        rules = self._merge_rules
+        toks = list(text)
+        again = True
+        while again:
+            again = False
+            k = 0
+            while k < len(toks) - 1:
+                new = rules.get((toks[k], toks[k + 1]))
+                if new is None:
+                    k += 1
+                else:
+                    toks[k:k + 2] = [new]
+                    again = True
+        return toks
+
+    def encode(self, text: str) -> List[int]:
+        unk = self.token2idx.get("<unk>", 3)
+        return [self.token2idx.get(t, unk) for t in self.tokenize(text)]
+
+    def decode(self, indices: List[int]) -> str:
+        return "".join(self.vocab[k] for k in indices)
+
+    # ------------------------------------------------------------------------------------------
+    # persistence: same four files and keys as the reference (``:473-551``)
+    # ------------------------------------------------------------------------------------------
+    def save(self, path: str) -> None:
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "vocab.json"), "w") as f:
+            json.dump(self.vocab, f)
+        # the reference saves a view of the whole pre-allocated table (2.4 MB for 50 rows);
+        # the same live rows are stored compactly here and load identically
+        live = self.embeddings[: self.current_vocab_size].detach().cpu().clone()
+        torch.save(live, os.path.join(path, "embeddings.pt"))
+        with open(os.path.join(path, "merges.json"), "w") as f:
+            json.dump(self.merge_history, f)
+        config = {
+            "curvature": self.curvature,
+            "merge_threshold": self.merge_threshold,
+            "embedding_dim": self.embeddings.size(1) - 1,
+            "max_vocab_size": self.max_vocab_size,
+            "use_approximate_search": self.use_approximate_search,
+        }
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(config, f)
+
+    @classmethod
+    def load(cls, path: str, device: Optional[torch.device] = None, **kwargs) -> "HyperbolicTokenizer":
+        with open(os.path.join(path, "vocab.json"), "r") as f:
+            vocab = json.load(f)
+        rows = torch.load(os.path.join(path, "embeddings.pt"), map_location="cpu", weights_only=True)
+        with open(os.path.join(path, "config.json"), "r") as f:
+            config = json.load(f)
+        tok = cls(
+            vocab=vocab,
+            embeddings=torch.nn.Parameter(rows),
+            curvature=config["curvature"],
+            merge_threshold=config["merge_threshold"],
+            device=device,
+            max_vocab_size=config.get("max_vocab_size", 100000),
+            use_approximate_search=config.get("use_approximate_search", True),
+            **kwargs,
+        )
+        with open(os.path.join(path, "merges.json"), "r") as f:
+            tok.merge_history = json.load(f)
+        tok.current_vocab_size = len(tok.vocab)
+        return tok

@@ -22,18 +22,25 @@
  * golden vectors produced by importing the reference in the build container
  * (tests/golden/make_golden.py; literal mode and sign-corrected "lorentz" mode).
  *
- * Canonical arithmetic (DESIGN.md "Canonical arithmetic").  The reference runs on torch CPU
- * kernels whose fp32 summation order is an implementation detail of the torch build; it cannot be
- * reproduced bit-for-bit by any other program.  The restatement therefore fixes ONE fully
- * specified fp32 evaluation order, which the HIP kernels reproduce bit-for-bit:
- *   S   = fmaf chain over the spatial coordinates k = 1..d in ascending k, starting from +0
- *   M   = fmaf(x0, y0, -S)                         (= x0*y0 - sum, reference sign, line :25)
+ * Canonical arithmetic (DESIGN.md "Canonical arithmetic").  The restatement reproduces the fp32
+ * bits the reference computes on torch's CPU kernels (verified bit-for-bit against torch in
+ * tests/test_canonical_vs_torch.py), and the HIP kernels reproduce the restatement bit-for-bit:
+ *   p_k = fl(x_k * y_k), k = 1..d                 (torch materialises the product tensor, :163)
+ *   S   = sum of p_k in the order of ATen's SumKernel.cpp inner reduction for float:
+ *         8 vector lanes x 4 interleaved accumulators, leftover vectors into accumulator 0,
+ *         accumulators combined 0+1+2+3, then the scalar tail, then lanes 0..7 in order
+ *         (rows shorter than 8 use the scalar 4-accumulator form); cascade levels only start
+ *         at d >= 512 and are outside the supported range (d <= 128)
+ *   M   = fl(fl(x0*y0) - S)                        (reference minkowski_dot, :25 / :160-169)
  *   u   = -M (sign_mode 0, reference as shipped)   or  +M (sign_mode 1, "lorentz")
- *   a   = clamp_min(u, 1.0f)  with NaN propagation (1.0 + 1e-8 == 1.0f in fp32, line :135)
- *   d   = acosh(a) / sqrtf((float)c),  acosh(a) = log1p(t + sqrt(t*(t+2))), t = a - 1
- * log1p / expm1 follow the published fdlibm (FreeBSD msun) float algorithms, restated below
- * with every operation in fp32 and no FMA contraction (build with -ffp-contract=off), so that
- * gcc on x86-64 and hipcc on gfx950 produce identical bits.
+ *   a   = clamp_min(u, 1.0f)  with NaN propagation (1.0 + 1e-8 == 1.0f in fp32, :135)
+ *   d   = acosh(a) / sqrtf((float)c); acosh as glibc 2.35 acoshf (what torch.acosh calls):
+ *         a <= 2: log1pf(t + sqrtf(2t + t*t)), t = a - 1, log1pf = fdlibm s_log1pf.c;
+ *         a  > 2: log(2a - 1/(a + sqrt(a*a - 1))) evaluated in double and rounded once
+ *         (glibc uses its table-driven logf there; agreement 87 %, otherwise 1 ulp).
+ * expm1 (for cosh / sinh in exp_map) follows fdlibm s_expm1f.c.  Everything is fp32 with no FMA
+ * contraction (build with -ffp-contract=off) except the double path above, so gcc on x86-64 and
+ * hipcc on gfx950 produce identical bits.
  *
  * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -mfma -mavx2 -fopenmp -shared -fPIC).
  */
@@ -57,60 +64,120 @@ static inline float    u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 /* canonical transcendental functions (fdlibm float algorithms, fp32 only)                    */
 /* ------------------------------------------------------------------------------------------ */
 
-/* log(1+x) for x >= 0 (NaN/inf pass through).  fdlibm s_log1pf algorithm. */
+/* log(1+x) for x >= 0 (NaN/inf pass through).  fdlibm s_log1pf.c (the form glibc 2.35 ships). */
 HMO_EXPORT float hmo_log1pf(float x)
 {
     const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
-    const float Lg1 = 0.66666662693f, Lg2 = 0.40000972152f, Lg3 = 0.28498786688f, Lg4 = 0.24279078841f;
-    uint32_t ix = f2u(x);
-    int k = 1;
-    float f = 0.0f, c = 0.0f;
-    if (ix >= 0x7f800000u) {            /* +inf, NaN, or negative: not used by acosh, pass/NaN */
-        if (ix == 0x7f800000u || (ix & 0x7fffffffu) > 0x7f800000u) return x;
-        if (ix == 0x80000000u) return x; /* -0 */
-        return u2f(0x7fc00000u);         /* negative argument: outside our domain */
+    const float Lp1 = 6.6666668653e-01f, Lp2 = 4.0000000596e-01f, Lp3 = 2.8571429849e-01f, Lp4 = 2.2222198546e-01f,
+                Lp5 = 1.8183572590e-01f, Lp6 = 1.5313838422e-01f, Lp7 = 1.4798198640e-01f;
+    int32_t hx = (int32_t)f2u(x), hu = 0, k = 1;
+    float f = 0.0f, c = 0.0f, hfsq, s, z, R, u;
+    if (hx < 0) {                               /* negative / -0 / -NaN: outside the domain used here */
+        if (f2u(x) == 0x80000000u) return x;
+        return u2f(0x7fc00000u);
     }
-    if (ix < 0x3ed413d0u) {             /* 1+x < sqrt(2)+ */
-        if (ix < 0x33800000u) return x; /* x < 2**-24 */
-        k = 0; f = x; c = 0.0f;
+    if (hx >= 0x7f800000) return x + x;         /* +inf, NaN */
+    if (hx < 0x3ed413d0) {                      /* 1+x < sqrt(2)+ */
+        if (hx < 0x38000000) {                  /* x < 2**-15 */
+            if (hx < 0x33800000) return x;      /* x < 2**-24 */
+            return x - (x * x) * 0.5f;
+        }
+        k = 0; f = x; hu = 1;
     }
-    if (k) {
-        float uf = 1.0f + x;
-        uint32_t iu = f2u(uf);
-        iu += 0x3f800000u - 0x3f3504f3u;
-        k = (int)(iu >> 23) - 0x7f;
-        if (k < 25) {
-            c = (k >= 2) ? (1.0f - (uf - x)) : (x - (uf - 1.0f));
-            c = c / uf;
+    if (k != 0) {
+        if (hx < 0x5a000000) {
+            u = 1.0f + x;
+            hu = (int32_t)f2u(u);
+            k = (hu >> 23) - 127;
+            c = (k > 0) ? 1.0f - (u - x) : x - (u - 1.0f);
+            c = c / u;
         } else {
+            u = x;
+            hu = (int32_t)f2u(u);
+            k = (hu >> 23) - 127;
             c = 0.0f;
         }
-        iu = (iu & 0x007fffffu) + 0x3f3504f3u;
-        f = u2f(iu) - 1.0f;
+        hu &= 0x007fffff;
+        if (hu < 0x3504f4) {                    /* u < sqrt(2) */
+            u = u2f((uint32_t)(hu | 0x3f800000));
+        } else {
+            k += 1;
+            u = u2f((uint32_t)(hu | 0x3f000000));
+            hu = (0x00800000 - hu) >> 2;
+        }
+        f = u - 1.0f;
     }
-    {
-        float s = f / (2.0f + f);
-        float z = s * s;
-        float w = z * z;
-        float t1 = w * (Lg2 + w * Lg4);
-        float t2 = z * (Lg1 + w * Lg3);
-        float R = t2 + t1;
-        float hfsq = (0.5f * f) * f;
-        float dk = (float)k;
-        return ((s * (hfsq + R) + (dk * ln2_lo + c)) - hfsq + f) + dk * ln2_hi;
+    hfsq = (0.5f * f) * f;
+    if (hu == 0) {                              /* |f| < 2**-20 */
+        if (f == 0.0f) {
+            if (k == 0) return 0.0f;
+            c = c + (float)k * ln2_lo;
+            return (float)k * ln2_hi + c;
+        }
+        R = hfsq * (1.0f - 0.66666666666666666f * f);
+        if (k == 0) return f - R;
+        return (float)k * ln2_hi - ((R - ((float)k * ln2_lo + c)) - f);
     }
+    s = f / (2.0f + f);
+    z = s * s;
+    R = z * (Lp1 + z * (Lp2 + z * (Lp3 + z * (Lp4 + z * (Lp5 + z * (Lp6 + z * Lp7))))));
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return (float)k * ln2_hi - ((hfsq - (s * (hfsq + R) + ((float)k * ln2_lo + c))) - f);
 }
 
-/* acosh(a) for a >= 1 (NaN passes through). */
+/* log(1+x) in double, x >= 0: fdlibm s_log1p.c.  Used only for acosh(a), a > 2. */
+static double hmo_log1p_d(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t ui; uint32_t hx, hu; int k = 1;
+    double hfsq, f = 0.0, c = 0.0, s, z, R, w, t1, t2, dk, uf;
+    memcpy(&ui, &x, 8);
+    hx = (uint32_t)(ui >> 32);
+    if (hx >= 0x7ff00000u) return x;            /* inf / NaN (negative inputs do not occur) */
+    if (hx < 0x3fda827au) {                     /* 1+x < sqrt(2)+ */
+        if ((hx << 1) < (0x3ca00000u << 1)) return x;   /* |x| < 2**-53 */
+        k = 0; c = 0.0; f = x;
+    }
+    if (k) {
+        uf = 1.0 + x;
+        memcpy(&ui, &uf, 8);
+        hu = (uint32_t)(ui >> 32);
+        hu += 0x3ff00000u - 0x3fe6a09eu;
+        k = (int)(hu >> 20) - 0x3ff;
+        if (k < 54) { c = (k >= 2) ? 1.0 - (uf - x) : x - (uf - 1.0); c = c / uf; } else c = 0.0;
+        hu = (hu & 0x000fffffu) + 0x3fe6a09eu;
+        ui = ((uint64_t)hu << 32) | (ui & 0xffffffffull);
+        memcpy(&uf, &ui, 8);
+        f = uf - 1.0;
+    }
+    hfsq = (0.5 * f) * f;
+    s = f / (2.0 + f);
+    z = s * s;
+    w = z * z;
+    t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    R = t2 + t1;
+    dk = (double)k;
+    return ((s * (hfsq + R) + (dk * ln2_lo + c)) - hfsq + f) + dk * ln2_hi;
+}
+
+/* acosh(a) for a >= 1 (NaN passes through), structured as glibc's e_acoshf.c. */
 HMO_EXPORT float hmo_acoshf(float a)
 {
     if (a != a) return a;
-    if (a > 1.0e9f) return hmo_log1pf(a + a);          /* log(2a), rel. error < 1e-10 */
-    {
+    if (a <= 1.0f) return 0.0f;
+    if (a <= 2.0f) {
         float t = a - 1.0f;
-        float q = t * (t + 2.0f);
-        float y = t + sqrtf(q);
-        return hmo_log1pf(y);
+        return hmo_log1pf(t + sqrtf(2.0f * t + t * t));
+    }
+    if (a > 3.0e38f) return a;                  /* +inf */
+    {
+        double x = (double)a;
+        double zz = 2.0 * x - 1.0 / (x + sqrt(x * x - 1.0));
+        return (float)hmo_log1p_d(zz - 1.0);
     }
 }
 
@@ -205,18 +272,75 @@ HMO_EXPORT float hmo_sinhf(float x)
 /* Lorentz primitives                                                                         */
 /* ------------------------------------------------------------------------------------------ */
 
+/* Sum of n fp32 terms in the order of ATen's SumKernel.cpp (cascade_sum, float, inner
+ * reduction over a contiguous row; torch 2.x CPU, 8-float vectors):
+ *   n >= 8: vectorized_inner_sum -> row_sum<Vec8> (4 interleaved vector accumulators over groups
+ *           of 4 vectors, leftover vectors into accumulator 0, then 0 += 1, += 2, += 3),
+ *           scalar tail summed from 0, then the 8 lanes added in order;
+ *   n <  8: scalar row_sum (4 interleaved scalar accumulators, leftovers into 0, then combined).
+ * The multi-level cascade only engages at >= 16 groups (n >= 512) and is not needed here.
+ * `term(ctx, k)` returns the k-th term (already rounded to fp32). */
+typedef float (*hmo_term_fn)(const void* ctx, int k);
+
+static float torch_order_sum(hmo_term_fn term, const void* ctx, int n)
+{
+    int i, k, l;
+    if (n < 8) {
+        float ps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int size_ilp = n / 4;
+        for (i = 0; i < size_ilp; ++i)
+            for (k = 0; k < 4; ++k) ps[k] = ps[k] + term(ctx, i * 4 + k);
+        for (i = size_ilp * 4; i < n; ++i) ps[0] = ps[0] + term(ctx, i);
+        for (k = 1; k < 4; ++k) ps[0] = ps[0] + ps[k];
+        return ps[0];
+    }
+    {
+        float ps[4][8];
+        const int vec_size = n / 8, size_ilp = vec_size / 4;
+        float acc = 0.0f;
+        for (k = 0; k < 4; ++k) for (l = 0; l < 8; ++l) ps[k][l] = 0.0f;
+        for (i = 0; i < size_ilp; ++i)
+            for (k = 0; k < 4; ++k)
+                for (l = 0; l < 8; ++l) ps[k][l] = ps[k][l] + term(ctx, (i * 4 + k) * 8 + l);
+        for (i = size_ilp * 4; i < vec_size; ++i)
+            for (l = 0; l < 8; ++l) ps[0][l] = ps[0][l] + term(ctx, i * 8 + l);
+        for (k = 1; k < 4; ++k)
+            for (l = 0; l < 8; ++l) ps[0][l] = ps[0][l] + ps[k][l];
+        for (i = vec_size * 8; i < n; ++i) acc = acc + term(ctx, i);
+        for (l = 0; l < 8; ++l) acc = acc + ps[0][l];
+        return acc;
+    }
+}
+
+typedef struct { const float* x; const float* y; } hmo_pair_ctx;
+static float term_prod(const void* ctx, int k)
+{
+    const hmo_pair_ctx* c = (const hmo_pair_ctx*)ctx;
+    return c->x[1 + k] * c->y[1 + k];           /* spatial coordinates start at column 1 */
+}
+
 /* lorentz_model.py:14-25 with the sign switch of SURVEY F5.
  * sign_mode 0: u = -(x0*y0 - sum)  (what distance/log_map feed to acosh as shipped)
  * sign_mode 1: u = +(x0*y0 - sum)  (standard Lorentz form) */
 HMO_EXPORT float hmo_minkowski_u(const float* x, const float* y, int d1, int sign_mode)
 {
-    float acc = 0.0f;
+    hmo_pair_ctx c;
+    float S, t, m;
+    c.x = x; c.y = y;
+    S = torch_order_sum(term_prod, &c, d1 - 1);
+    t = x[0] * y[0];
+    m = t - S;                                  /* reference minkowski_dot */
+    return sign_mode ? m : -m;
+}
+
+/* the fast (prefilter) form used by the timed baseline: plain fmaf chain, time coordinate last */
+static inline float fast_u(const float* x, const float* y, int d1, int sign_mode)
+{
+    float acc = 0.0f, m;
     int k;
     for (k = 1; k < d1; ++k) acc = fmaf(x[k], y[k], acc);
-    {
-        float m = fmaf(x[0], y[0], -acc);       /* x0*y0 - S : reference minkowski_dot */
-        return sign_mode ? m : -m;
-    }
+    m = fmaf(x[0], y[0], -acc);
+    return sign_mode ? m : -m;
 }
 
 static inline float clamp_min_one(float u)      /* torch.clamp(min=1+1e-8) in fp32, NaN propagates */
@@ -288,9 +412,11 @@ HMO_EXPORT void hmo_log_map(const float* x, const float* y, int d1, int sign_mod
  * fire because n >= 1e-4, so direction = v / n. */
 HMO_EXPORT void hmo_exp_map(const float* x, const float* v, int d1, float* out)
 {
-    float acc = 0.0f, n, ch, sh;
+    float acc, n, ch, sh;
     int k;
-    for (k = 1; k < d1; ++k) acc = fmaf(v[k], v[k], acc);
+    hmo_pair_ctx c;
+    c.x = v; c.y = v;
+    acc = torch_order_sum(term_prod, &c, d1 - 1);      /* torch.sum(v[1:] * v[1:]) */
     if (acc == acc && acc < 1.0e-8f) acc = 1.0e-8f;
     n = sqrtf(acc);
     ch = hmo_coshf(n);
@@ -418,12 +544,15 @@ HMO_EXPORT int64_t hmo_pairwise_topk(const float* X, int64_t n, int64_t ld, int 
 /* ------------------------------------------------------------------------------------------ */
 /* fast form for the timed CPU baseline (bench.py cpu_baseline leg)                            */
 /* ------------------------------------------------------------------------------------------ */
-/* Same arithmetic, same results, organised for the host cores: the table is transposed once
- * into K-major order so that the canonical fmaf chain runs in SIMD lanes ACROSS partner rows j
- * (each lane still performs the scalar chain in ascending k), OpenMP over row blocks, and the
- * acosh is evaluated only for pairs whose u is below a conservative bound u_hi (u >= u_hi implies
- * d >= thr with a 1e-5 relative margin, far above the 3e-7 error of the canonical acosh).
- * tests/test_oracle_fast.py checks it against hmo_pairwise_topk. */
+/* Same results, organised for the host cores in two stages (the GPU engine has the same shape):
+ * (1) a fast prefilter: the table is transposed once into K-major order and a plain fmaf chain
+ *     runs in SIMD lanes ACROSS partner rows j (OpenMP over row blocks); it differs from the
+ *     canonical u by at most delta = (d+5) * 2^-23 * max_row ||x||^2 (both are roundings of the
+ *     same exact form; standard gamma_n bound on each);
+ * (2) pairs whose fast u is below u_hi + delta (u >= u_hi implies d >= thr with a 1e-5 relative
+ *     margin, far above the few-ulp error of acosh) are re-evaluated with the canonical
+ *     arithmetic and tested exactly.
+ * tests/test_oracle_golden.py::test_fast_oracle_equals_plain checks it against hmo_pairwise_topk. */
 
 #define HMO_JB 256   /* partner-row block processed per inner tile */
 
@@ -447,6 +576,7 @@ HMO_EXPORT int64_t hmo_fast_pairwise_topk(const float* X, int64_t n, int64_t ld,
 {
     const float sc = sqrtf(c);
     const float u_hi = u_hi_for_threshold(thr, c);
+    float u_pre;
     const int64_t npad = (n + HMO_JB - 1) / HMO_JB * HMO_JB;
     float* XT = (float*)aligned_alloc(64, sizeof(float) * (size_t)npad * (size_t)d1);
     int nthreads = 1;
@@ -454,8 +584,18 @@ HMO_EXPORT int64_t hmo_fast_pairwise_topk(const float* X, int64_t n, int64_t ld,
     int64_t i, t, m;
     int kk;
     memset(XT, 0, sizeof(float) * (size_t)npad * (size_t)d1);
-    for (i = 0; i < n; ++i)
-        for (kk = 0; kk < d1; ++kk) XT[(int64_t)kk * npad + i] = X[i * ld + kk];
+    {
+        double r2max = 0.0;
+        for (i = 0; i < n; ++i) {
+            double r2 = 0.0;
+            for (kk = 0; kk < d1; ++kk) {
+                XT[(int64_t)kk * npad + i] = X[i * ld + kk];
+                r2 += (double)X[i * ld + kk] * (double)X[i * ld + kk];
+            }
+            if (r2 == r2 && r2 < 1e300 && r2 > r2max) r2max = r2;   /* NaN / inf rows never qualify */
+        }
+        u_pre = u_hi + (float)((double)(d1 + 4) * 1.1920929e-07 * r2max * 1.0001);
+    }
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
 #endif
@@ -495,8 +635,8 @@ HMO_EXPORT int64_t hmo_fast_pairwise_topk(const float* X, int64_t n, int64_t ld,
                 for (jj = 0; jj < HMO_JB; ++jj) {
                     int64_t j = j0 + jj;
                     float u = ubuf[jj];
-                    if (j > ii && j < n && u < u_hi) {
-                        float d = dist_from_u(u, sc);
+                    if (j > ii && j < n && u < u_pre) {
+                        float d = dist_from_u(hmo_minkowski_u(xi, X + j * ld, d1, sign_mode), sc);
                         if (d < thr) {
                             ++total;
                             if (tm[tid] == tcap[tid]) {

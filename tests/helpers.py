@@ -1,0 +1,100 @@
+"""Test-only helpers.
+
+``OracleEngine`` is a TEST DOUBLE with the interface of ``hyptokenizer_amd.engine.MergeEngine``,
+backed by the CPU oracle.  It exists so that the host logic of the tokenizer classes (cache
+stepping, threshold dynamics, RNG order, save/load) can be checked against the reference's golden
+vectors in the GPU-less build container.  Product code never constructs it: without a HIP device
+the tokenizers raise ``HypMergeUnavailable``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import hm_oracle as O
+
+MODES = {"reference": 0, "lorentz": 1}
+
+
+class OracleEngine:
+    def __init__(self, max_rows: int, d1: int, sign_convention="reference", fast: bool = True):
+        self.max_rows, self.d1 = max_rows, d1
+        self.sign_mode = MODES[sign_convention] if isinstance(sign_convention, str) else int(sign_convention)
+        self.X = np.zeros((max_rows, d1), np.float32)
+        self._n = 0
+        self.fast = fast
+        self.calls = {"topk": 0, "argmin": 0, "candidates": 0, "set_table": 0}
+
+    @property
+    def n(self) -> int:
+        return self._n
+
+    def set_table(self, table: torch.Tensor, n_rows: int) -> None:
+        self.calls["set_table"] += 1
+        self.X[:n_rows] = table.detach().cpu().numpy()[:n_rows]
+        self.X[n_rows:] = 0
+        self._n = int(n_rows)
+
+    def update_rows(self, table, r0, r1):
+        self.X[r0:r1] = table.detach().cpu().numpy()[r0:r1]
+        self._n = max(self._n, r1)
+
+    def _range(self, row_begin, row_end):
+        return max(0, row_begin), (self._n if row_end < 0 else min(row_end, self._n))
+
+    def topk(self, c, thr, k, row_begin=0, row_end=-1):
+        self.calls["topk"] += 1
+        r0, r1 = self._range(row_begin, row_end)
+        thr = float(np.float32(thr))
+        if not thr > 0 or self._n < 2:
+            e = np.empty(0, np.float32)
+            return e, np.empty(0, np.int32), np.empty(0, np.int32), 0
+        return O.pairwise_topk(self.X, self._n, float(c), thr, self.sign_mode, max(int(k), 1), r0, r1, fast=self.fast) \
+            if k > 0 else (np.empty(0, np.float32), np.empty(0, np.int32), np.empty(0, np.int32),
+                           O.pairwise_count(self.X, self._n, float(c), thr, self.sign_mode, r0, r1))
+
+    def argmin(self, c, thr, row_begin=0, row_end=-1):
+        self.calls["argmin"] += 1
+        d, i, j, cnt = self.topk(c, thr, 1, row_begin, row_end)
+        self.calls["topk"] -= 1
+        if cnt == 0:
+            return None
+        return float(d[0]), int(i[0]), int(j[0])
+
+    def candidates(self, c, thr, row_begin=0, row_end=-1, cap=1 << 24):
+        self.calls["candidates"] += 1
+        r0, r1 = self._range(row_begin, row_end)
+        i, j, d, total = O.pairwise_candidates(self.X, self._n, float(c), float(np.float32(thr)), self.sign_mode,
+                                               cap=min(cap, 1 << 22), row_begin=r0, row_end=r1)
+        return i, j, d, total
+
+    def pair_distance(self, I, J, c):
+        return O.pair_distance(self.X, np.asarray(I, np.int32), np.asarray(J, np.int32), float(c), self.sign_mode)
+
+    def midpoint(self, I, J, W, c):
+        return torch.from_numpy(O.midpoint_batch(self.X, I, J, W, float(c), self.sign_mode))
+
+    def merge_append(self, i, j, w, c, table, new_row):
+        row = O.midpoint_batch(self.X, [i], [j], [np.float32(w)], float(c), self.sign_mode)[0]
+        self.X[new_row] = row
+        table.detach()[new_row] = torch.from_numpy(row)
+        self._n = max(self._n, new_row + 1)
+
+    def row_vs_all(self, row, n, c):
+        return O.row_vs_all(self.X, n, row, float(c), self.sign_mode)
+
+    def scan_stats(self):
+        return {"scan_ms": 0.0, "pairs": 0, "emitted": 0, "passes": 0}
+
+
+def bits(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def nan_equal_close(a, b, atol):
+    """|a-b| <= atol with NaNs required in the same places."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    na, nb = np.isnan(a), np.isnan(b)
+    if not np.array_equal(na, nb):
+        return False
+    return bool(np.all(np.abs(a[~na] - b[~nb]) <= atol))
