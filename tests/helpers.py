@@ -98,3 +98,25 @@ def nan_equal_close(a, b, atol):
     if not np.array_equal(na, nb):
         return False
     return bool(np.all(np.abs(a[~na] - b[~nb]) <= atol))
+
+
+# ----------------------------------------------------------------------------------------------
+# oracle-backed stand-ins for the device functions of hyptokenizer_amd.embedding.lorentz_model,
+# used by CPU tests of callers (CLI) only
+# ----------------------------------------------------------------------------------------------
+def oracle_exp_map(x, v, c=1.0):
+    shape = torch.broadcast_shapes(x.shape, v.shape)
+    xb = x.expand(shape).reshape(-1, shape[-1]).numpy()
+    vb = v.expand(shape).reshape(-1, shape[-1]).numpy()
+    return torch.from_numpy(O.exp_map(xb, vb)).reshape(shape)
+
+
+def oracle_project(x, c=1.0):
+    return torch.from_numpy(O.project(x.reshape(-1, x.shape[-1]).numpy(), float(c))).reshape(x.shape)
+
+
+def oracle_distance(x, y, c=1.0, *, sign_convention="reference"):
+    shape = torch.broadcast_shapes(x.shape, y.shape)
+    xb = x.expand(shape).reshape(-1, shape[-1]).contiguous().numpy()
+    yb = y.expand(shape).reshape(-1, shape[-1]).contiguous().numpy()
+    return torch.from_numpy(O.distance(xb, yb, float(c), MODES[sign_convention])).reshape(shape[:-1])
