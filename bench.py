@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Headline benchmark of the MI355X merge engine (BASELINE.json metric:
+"merge-steps/sec + pairwise Lorentz-dist GB/s, V=50k d=100, 1/2/4/8 GPU").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE merge iteration of ``HyperbolicTokenizer.optimize_merges`` (reference
+``tokenizer/hyperbolic_merge.py:357-412``): a full all-pairs Lorentz-distance search for the
+nearest pair below the threshold, then the log-map/exp-map midpoint appended as a new row.
+Workload: V = 50 000 synthetic Lorentz rows, d = 100, fp32, curvature 1, sign-corrected Minkowski
+form ("lorentz": the mode in which the search is non-degenerate), threshold 0.5.
+Inputs are resident in HBM before the timed region.  With N > 1 ranks the rows of the pair
+triangle are sharded over the ranks (equal pair counts), each rank scans its share of the SAME
+problem (strong scaling), the best records are all-gathered over RCCL and every rank applies the
+merge to its replica.
+
+One JSON line on rank 0; see README/DESIGN.md for the fields.  `roofline` is for the dominant
+kernel (hm_scan_kernel, fp32 MFMA): achieved = N(N-1)(d+1) flops per launch (triangle only; the
+reference's dense convention would be 2x) / the launch duration measured with HIP events on the
+launch stream inside the timed region.  `cpu_baseline` times the oracle's OpenMP restatement of
+the same search on a bounded row sample on this host's cores (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("TQDM_DISABLE", "1")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+V, D, SCALE, SEED, THR, CURV = 50000, 100, 0.05, 42, 0.5, 1.0
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(X: np.ndarray, device, budget_s: float = 12.0) -> dict:
+    """Time the oracle (CPU restatement, OpenMP) on rows [0, R) of the same search and extrapolate
+    by pair count; check that the GPU returns the identical pair for the same row range."""
+    from oracle import hm_oracle as O
+    from hyptokenizer_amd.engine import MergeEngine
+    O.build()
+    n = X.shape[0]
+    cores = O.num_threads()
+    gpu_engine = MergeEngine(n + 8, X.shape[1], "lorentz", device)
+    table = torch.zeros((n + 8, X.shape[1]), dtype=torch.float32, device=device)
+    table[:n] = torch.from_numpy(X).to(device)
+    gpu_engine.set_table(table, n)
+
+    def pairs(r):
+        return r * (n - 1) - (r - 1) * r // 2
+
+    O.pairwise_topk(X, n, CURV, THR, 1, 1, 0, 64, fast=True)              # warm (page in, thread pool)
+    r = 1024
+    t0 = time.perf_counter()
+    O.pairwise_topk(X, n, CURV, THR, 1, 1, 0, r, fast=True)
+    t_cal = time.perf_counter() - t0
+    rows = int(min(n - 1, max(r, r * budget_s / max(t_cal, 1e-3))))
+    rows = max(256, rows // 256 * 256)
+    t0 = time.perf_counter()
+    od, oi, oj, oc = O.pairwise_topk(X, n, CURV, THR, 1, 1, 0, rows, fast=True)
+    t = time.perf_counter() - t0
+    frac = pairs(rows) / pairs(n - 1)
+    est_scan_s = t / frac
+    g = gpu_engine.argmin(CURV, THR, 0, rows)
+    same = (g is None and oc == 0) or (g is not None and oc > 0 and (g[1], g[2]) == (int(oi[0]), int(oj[0]))
+                                       and np.float32(g[0]).view(np.uint32) == od[:1].view(np.uint32)[0])
+    return {
+        "value": 1.0 / est_scan_s, "unit": "merges/s", "cores": cores, "kind": "port",
+        "sample": f"rows [0,{rows}) of the V={n} d={D} search = {100 * frac:.1f}% of all pairs in {t:.2f} s, "
+                  f"extrapolated by pair count (midpoint cost negligible)",
+        "gflops": 2.0 * pairs(rows) * (D + 1) / t / 1e9,
+        "same_pair_as_gpu_on_sample": bool(same),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the merge engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    shard = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        from hyptokenizer_amd.sharding import ShardContext
+        shard = ShardContext(device=device)
+
+    from hyptokenizer_amd.synthetic import cjk_vocab, lorentz_table
+    from hyptokenizer_amd.tokenizer.fast_hyperbolic_merge import FastHyperbolicTokenizer
+    from hyptokenizer_amd.tokenizer.hyperbolic_merge import HyperbolicTokenizer
+
+    X = lorentz_table(V, D, seed=SEED, scale=SCALE)
+    vocab = cjk_vocab(V)
+    steps_total = args.steps + args.warmup
+    tok = HyperbolicTokenizer(vocab, torch.nn.Parameter(X), curvature=CURV, merge_threshold=THR, device=device,
+                              max_vocab_size=V + steps_total + 64, sign_convention="lorentz", shard=shard)
+    eng = tok._get_engine()                      # builds the scan image: inputs resident before timing
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tok.optimize_merges(steps=args.warmup, log_every=10 ** 9)
+    eng.scan_totals(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    tok.optimize_merges(steps=args.steps, log_every=10 ** 9)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    merges_done = len(tok.merge_history) - args.warmup
+    tot = eng.scan_totals()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        agg = torch.tensor([tot["scan_ms"], float(tot["pairs"]), float(tot["launches"])], dtype=torch.float64, device=device)
+        lst = [torch.zeros_like(agg) for _ in range(world)]
+        dist.all_gather(lst, agg)
+        per_rank = [x.cpu().tolist() for x in lst]
+    else:
+        per_rank = [[tot["scan_ms"], float(tot["pairs"]), float(tot["launches"])]]
+
+    # fast-path figure (FastHyperbolicTokenizer semantics: one exact top-10000 search per ~101 steps)
+    fast = None
+    if rank == 0 or world > 1:
+        fsteps = 1010
+        ftok = FastHyperbolicTokenizer(vocab, torch.nn.Parameter(X), curvature=CURV, merge_threshold=THR, device=device,
+                                       max_vocab_size=V + fsteps + 64, sign_convention="lorentz", shard=shard)
+        ftok._get_engine()
+        ftok.optimize_merges(steps=101, log_every=10 ** 9, adaptive_threshold=False)
+        barrier()
+        tf0 = time.perf_counter()
+        ftok.optimize_merges(steps=fsteps - 101, log_every=10 ** 9, adaptive_threshold=False)
+        barrier()
+        tf = time.perf_counter() - tf0
+        fast = {"merges_per_s": (len(ftok.merge_history) - 101) / tf, "steps": fsteps - 101,
+                "note": "FastHyperbolicTokenizer.optimize_merges: cache of 10000, one exact top-k search per ~101 steps"}
+
+    if rank == 0:
+        launches = sum(p[2] for p in per_rank)
+        avg_ms = sum(p[0] for p in per_rank) / max(launches, 1.0)           # mean launch duration
+        flops_per_launch = 2.0 * (D + 1) * sum(p[1] for p in per_rank) / max(launches, 1.0)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        n_mid = V + args.warmup + args.steps / 2.0
+        scan_ms_per_step = max(p[0] / max(p[2], 1.0) for p in per_rank)     # slowest rank's scan per step
+        out = {
+            "metric": "merge_steps_per_sec",
+            "value": merges_done / elapsed,
+            "unit": "merges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"HyperbolicTokenizer.optimize_merges, full all-pairs search every step, V={V} d={D} "
+                                   f"fp32, lorentz sign, thr={THR}, c={CURV}, scale={SCALE}, seed={SEED}",
+                       "vocab": V, "dim": D, "merge_threshold": THR, "parallelism": f"rows sharded over {world} rank(s)"},
+            "pairwise_dist_GBps_effective": (n_mid * n_mid * 4.0) / (scan_ms_per_step * 1e-3) / 1e9,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "hm_scan_kernel<25,1,ARGMIN>", "avg_launch_ms": avg_ms,
+                         "flops_per_launch": flops_per_launch, "launches": launches},
+            "fast_path": fast,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(X.numpy(), device)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

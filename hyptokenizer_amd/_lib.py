@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = (
     "hm_update_rows", "hm_rows", "hm_pairwise_argmin", "hm_pairwise_topk", "hm_pairwise_candidates",
     "hm_row_vs_all", "hm_pair_distance", "hm_midpoint_batch", "hm_merge_append", "hm_batch_distance",
     "hm_rows_minkowski", "hm_rows_distance", "hm_rows_log_map", "hm_rows_exp_map", "hm_rows_project",
-    "hm_last_scan_stats",
+    "hm_last_scan_stats", "hm_scan_totals",
 )
 
 
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     L.hm_rows_exp_map.argtypes = [vp, vp, i64, i64, C.c_int, vp, i64, vp]
     L.hm_rows_project.argtypes = [vp, i64, i64, C.c_int, f32, vp, i64, vp]
     L.hm_last_scan_stats.argtypes = [vp, pf32, pi64, pi64, pi32]
+    L.hm_scan_totals.argtypes = [vp, C.POINTER(C.c_double), pi64, pi64, C.c_int]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("hm_last_error", "hm_rows"):

@@ -772,6 +772,8 @@ struct hm_engine {
     float last_scan_ms = 0.f;
     int64_t last_pairs = 0, last_emitted = 0;
     int last_passes = 0;
+    double tot_scan_ms = 0.0;
+    int64_t tot_pairs = 0, tot_launches = 0;
     std::string err;
 };
 
@@ -1070,6 +1072,7 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
         e->last_scan_ms += ms;
         e->last_passes += 1;
         e->last_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
+        e->tot_scan_ms += ms; e->tot_pairs += e->last_pairs; e->tot_launches += 1;
         e->last_emitted = e->h->ctr[0];
         if (e->h->ctr[0] <= e->ent_cap) break;
         // overflow: the running key is the exact minimum over all published waves; rerun bounded by it
@@ -1230,6 +1233,7 @@ static int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row
         e->last_scan_ms += ms;
         e->last_passes += 1;
         e->last_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
+        e->tot_scan_ms += ms; e->tot_pairs += e->last_pairs; e->tot_launches += 1;
         e->last_emitted = e->h->ctr[0];
         if (e->h->ctr[4] != 0)
             return hm_fail(e, HM_E_STATE, "pair scan: prefilter margin violated (an entry classified as surely below the "
@@ -1484,5 +1488,15 @@ extern "C" int hm_last_scan_stats(const hm_engine* e, float* scan_ms, int64_t* p
     if (pairs) *pairs = e->last_pairs;
     if (emitted) *emitted = e->last_emitted;
     if (passes) *passes = e->last_passes;
+    return HM_OK;
+}
+
+extern "C" int hm_scan_totals(hm_engine* e, double* scan_ms, int64_t* pairs, int64_t* launches, int reset)
+{
+    if (!e) return HM_E_ARG;
+    if (scan_ms) *scan_ms = e->tot_scan_ms;
+    if (pairs) *pairs = e->tot_pairs;
+    if (launches) *launches = e->tot_launches;
+    if (reset) { e->tot_scan_ms = 0.0; e->tot_pairs = 0; e->tot_launches = 0; }
     return HM_OK;
 }

@@ -177,6 +177,12 @@ class MergeEngine:
         return {"scan_ms": float(ms.value), "pairs": int(pairs.value), "emitted": int(emitted.value),
                 "passes": int(passes.value)}
 
+    def scan_totals(self, reset: bool = False) -> dict:
+        """Summed event-timed duration / pairs / launches of the pair-scan kernel (bench roofline)."""
+        ms, pairs, launches = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        self._L.hm_scan_totals(self._h, C.byref(ms), C.byref(pairs), C.byref(launches), 1 if reset else 0)
+        return {"scan_ms": float(ms.value), "pairs": int(pairs.value), "launches": int(launches.value)}
+
 
 # ----------------------------------------------------------------------------------------------
 # engine-independent device functions (embedding/lorentz_model.py surface)

@@ -143,11 +143,12 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         *,
         sign_convention: str = "reference",
         engine=None,
+        shard=None,
     ):
         super().__init__(vocab=vocab, embeddings=embeddings, curvature=curvature, merge_threshold=merge_threshold,
                          lr=lr, device=device, max_vocab_size=max_vocab_size,
                          use_approximate_search=use_approximate_search, sign_convention=sign_convention,
-                         engine=engine)
+                         engine=engine, shard=shard)
         self.index = None
         self.index_outdated = True
         self.cache = AdaptiveMergeCache(max_size=cache_size)
@@ -174,7 +175,11 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         if cached:
             return cached
         eng = self._get_engine()
-        d, i, j, total = eng.topk(self.curvature, self._search_threshold(), self.cache.max_size)
+        if self.shard is not None:
+            from ..sharding import sharded_topk
+            d, i, j, total = sharded_topk(eng, self.shard, self.curvature, self._search_threshold(), self.cache.max_size)
+        else:
+            d, i, j, total = eng.topk(self.curvature, self._search_threshold(), self.cache.max_size)
         found = CandidateList(d, i, j, total)
         self.cache.add_batch(found)
         return found

@@ -12,7 +12,9 @@ What a step computes is unchanged:
 
 Additive keyword-only arguments: ``sign_convention`` ("reference" = arithmetic as shipped, the
 default; "lorentz" = sign-corrected) and ``engine`` (an object with the
-``MergeEngine`` interface; tests inject an oracle-backed double, the product never does).
+``MergeEngine`` interface; tests inject an oracle-backed double, the product never does) and
+``shard`` (a ``hyptokenizer_amd.sharding.ShardContext``: the candidate search is row-sharded over
+the ranks of a process group and every rank applies the same merge to its replica).
 The FAISS pre-filter of the reference (``:203-244``, ``:593-625``) is replaced by the exact GPU
 search and never used: ``FAISS_AVAILABLE`` is always False here.
 """
@@ -69,6 +71,7 @@ class HyperbolicTokenizer:
         *,
         sign_convention: str = "reference",
         engine=None,
+        shard=None,
     ):
         if device is None:
             device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -94,6 +97,7 @@ class HyperbolicTokenizer:
 
         self._engine = engine
         self._engine_key = None       # (table identity, version, rows) the engine image was built from
+        self.shard = shard            # hyptokenizer_amd.sharding.ShardContext: row-sharded search over ranks
 
     # ------------------------------------------------------------------------------------------
     # engine plumbing
@@ -145,7 +149,11 @@ class HyperbolicTokenizer:
 
     def _best_candidate(self) -> Optional[Tuple[int, int, float]]:
         """``sorted(candidates, key=distance)[0]`` without building the list."""
-        hit = self._get_engine().argmin(self.curvature, self._search_threshold())
+        if self.shard is not None:
+            from ..sharding import sharded_argmin
+            hit = sharded_argmin(self._get_engine(), self.shard, self.curvature, self._search_threshold())
+        else:
+            hit = self._get_engine().argmin(self.curvature, self._search_threshold())
         if hit is None:
             return None
         d, i, j = hit

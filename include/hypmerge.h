@@ -139,6 +139,11 @@ int hm_rows_project(const float* x_dev, int64_t b, int64_t ld, int d1, float c, 
  * *scan_ms = duration of the dominant pair-scan kernel launch(es); *pairs = pairs it covered. */
 int hm_last_scan_stats(const hm_engine* e, float* scan_ms, int64_t* pairs, int64_t* emitted, int32_t* passes);
 
+/* Running totals over every pair-scan launch (argmin / top-k modes, not the sampled estimate
+ * passes) since engine creation or the last reset: summed event-timed kernel duration, pairs
+ * covered and number of launches.  reset != 0 clears the totals after reading. */
+int hm_scan_totals(hm_engine* e, double* scan_ms, int64_t* pairs, int64_t* launches, int reset);
+
 #ifdef __cplusplus
 }
 #endif

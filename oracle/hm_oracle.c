@@ -555,6 +555,7 @@ HMO_EXPORT int64_t hmo_pairwise_topk(const float* X, int64_t n, int64_t ld, int 
  * tests/test_oracle_golden.py::test_fast_oracle_equals_plain checks it against hmo_pairwise_topk. */
 
 #define HMO_JB 256   /* partner-row block processed per inner tile */
+#define HMO_IB 4     /* stationary rows sharing each partner-column load */
 
 static float u_hi_for_threshold(float thr, float c)
 {
@@ -605,52 +606,63 @@ HMO_EXPORT int64_t hmo_fast_pairwise_topk(const float* X, int64_t n, int64_t ld,
 #pragma omp parallel reduction(+ : total)
     {
         int tid = 0;
-        float ubuf[HMO_JB] __attribute__((aligned(64)));
-        int64_t ii;
+        float ubuf[HMO_IB][HMO_JB] __attribute__((aligned(64)));
+        int64_t ib;
+        const int64_t nblk = (row_end - row_begin + HMO_IB - 1) / HMO_IB;
 #ifdef _OPENMP
         tid = omp_get_thread_num();
 #endif
         tcap[tid] = 1 << 14;
         tbuf[tid] = (hmo_cand*)malloc(sizeof(hmo_cand) * (size_t)tcap[tid]);
-#pragma omp for schedule(dynamic, 8)
-        for (ii = row_begin; ii < row_end; ++ii) {
-            const float* xi = X + ii * ld;
+#pragma omp for schedule(dynamic, 4)
+        for (ib = 0; ib < nblk; ++ib) {
+            const int64_t i0 = row_begin + ib * HMO_IB;
+            const int nrow = (int)((row_end - i0) < HMO_IB ? (row_end - i0) : HMO_IB);
+            const float* xr[HMO_IB];
             int64_t j0;
-            for (j0 = (ii + 1) / HMO_JB * HMO_JB; j0 < n; j0 += HMO_JB) {
+            int q;
+            for (q = 0; q < HMO_IB; ++q) xr[q] = X + (i0 + (q < nrow ? q : 0)) * ld;
+            for (j0 = (i0 + 1) / HMO_JB * HMO_JB; j0 < n; j0 += HMO_JB) {
                 int jj, k2;
-                for (jj = 0; jj < HMO_JB; ++jj) ubuf[jj] = 0.0f;
+                for (q = 0; q < HMO_IB; ++q)
+                    for (jj = 0; jj < HMO_JB; ++jj) ubuf[q][jj] = 0.0f;
                 for (k2 = 1; k2 < d1; ++k2) {
-                    const float xv = xi[k2];
                     const float* col = XT + (int64_t)k2 * npad + j0;
-                    for (jj = 0; jj < HMO_JB; ++jj) ubuf[jj] = fmaf(xv, col[jj], ubuf[jj]);
+                    const float x0v = xr[0][k2], x1v = xr[1][k2], x2v = xr[2][k2], x3v = xr[3][k2];
+                    for (jj = 0; jj < HMO_JB; ++jj) {
+                        const float cv = col[jj];
+                        ubuf[0][jj] = fmaf(x0v, cv, ubuf[0][jj]);
+                        ubuf[1][jj] = fmaf(x1v, cv, ubuf[1][jj]);
+                        ubuf[2][jj] = fmaf(x2v, cv, ubuf[2][jj]);
+                        ubuf[3][jj] = fmaf(x3v, cv, ubuf[3][jj]);
+                    }
                 }
-                {
+                for (q = 0; q < nrow; ++q) {
+                    const int64_t ii = i0 + q;
+                    const float* xi = xr[q];
                     const float x0 = xi[0];
                     const float* col = XT + j0;
                     for (jj = 0; jj < HMO_JB; ++jj) {
-                        float mm = fmaf(x0, col[jj], -ubuf[jj]);
-                        ubuf[jj] = sign_mode ? mm : -mm;
-                    }
-                }
-                for (jj = 0; jj < HMO_JB; ++jj) {
-                    int64_t j = j0 + jj;
-                    float u = ubuf[jj];
-                    if (j > ii && j < n && u < u_pre) {
-                        float d = dist_from_u(hmo_minkowski_u(xi, X + j * ld, d1, sign_mode), sc);
-                        if (d < thr) {
-                            ++total;
-                            if (tm[tid] == tcap[tid]) {
-                                qsort(tbuf[tid], (size_t)tm[tid], sizeof(hmo_cand), cand_cmp);
-                                if (tm[tid] > k) tm[tid] = k;
-                                if (tm[tid] * 2 > tcap[tid]) {
-                                    tcap[tid] *= 2;
-                                    tbuf[tid] = (hmo_cand*)realloc(tbuf[tid], sizeof(hmo_cand) * (size_t)tcap[tid]);
+                        const int64_t j = j0 + jj;
+                        const float mm = fmaf(x0, col[jj], -ubuf[q][jj]);
+                        const float u = sign_mode ? mm : -mm;
+                        if (j > ii && j < n && u < u_pre) {
+                            float d = dist_from_u(hmo_minkowski_u(xi, X + j * ld, d1, sign_mode), sc);
+                            if (d < thr) {
+                                ++total;
+                                if (tm[tid] == tcap[tid]) {
+                                    qsort(tbuf[tid], (size_t)tm[tid], sizeof(hmo_cand), cand_cmp);
+                                    if (tm[tid] > k) tm[tid] = k;
+                                    if (tm[tid] * 2 > tcap[tid]) {
+                                        tcap[tid] *= 2;
+                                        tbuf[tid] = (hmo_cand*)realloc(tbuf[tid], sizeof(hmo_cand) * (size_t)tcap[tid]);
+                                    }
                                 }
+                                tbuf[tid][tm[tid]].dbits = f2u(d);
+                                tbuf[tid][tm[tid]].i = (int32_t)ii;
+                                tbuf[tid][tm[tid]].j = (int32_t)j;
+                                ++tm[tid];
                             }
-                            tbuf[tid][tm[tid]].dbits = f2u(d);
-                            tbuf[tid][tm[tid]].i = (int32_t)ii;
-                            tbuf[tid][tm[tid]].j = (int32_t)j;
-                            ++tm[tid];
                         }
                     }
                 }
