@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must come first: it ships its own HIP runtime (libamdhip64) and libhypmerge.so has to bind
+# to that one.  Loading our library first would pull in the system runtime and leave the process
+# with two HIP runtimes (the second one then reports "no device").
+import torch  # noqa: F401  (side effect: loads torch's libamdhip64)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhypmerge.so")
 
