@@ -39,7 +39,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------
 // constants
 // ------------------------------------------------------------------------------------------------
-#define HM_ROWS_PER_BLOCK 256      // 4 waves x 64 stationary rows
+#ifndef HM_ODD_STRIDE
+#define HM_ODD_STRIDE 1            // pad image rows to an odd number of 16-byte chunks (LDS bank spread)
+#endif
+#ifndef HM_PREFETCH_B
+#define HM_PREFETCH_B 1            // fetch B fragments one k-group ahead of their MFMAs
+#endif
+#ifndef HM_CHUNK_TILES
+#define HM_CHUNK_TILES 32          // column tiles per block (upper bound; shrunk for small tables)
+#endif
+#ifndef HM_TAIL_FRACTION
+#define HM_TAIL_FRACTION 0.15      // share of the work issued last in quarter-size chunks
+#endif
+#ifndef HM_DMA_INTERLEAVE
+#define HM_DMA_INTERLEAVE 1        // issue the next tile's LDS-DMA between MFMAs instead of ahead of them
+#endif
+#ifndef HM_MIN_WAVES
+#define HM_MIN_WAVES 2             // __launch_bounds__ second argument (waves per SIMD): 2 blocks per CU
+#endif
+#ifndef HM_TM
+#define HM_TM 1                    // 32-row MFMA tiles per wave along the stationary rows (1 or 2)
+#endif
+#define HM_WAVE_ROWS (32 * HM_TM)
+#define HM_ROWS_PER_BLOCK (4 * HM_WAVE_ROWS)   // 4 waves
 #define HM_COLS_PER_TILE 64        // partner rows per LDS tile
 #define HM_TIE_SLACK 1024u         // ulps of u' that are treated as "may still order before" (d is 2.5-ulp monotone)
 #define HM_MODE_TOPK 0
@@ -53,9 +75,13 @@ struct ScanArgs {
     const float* img;
     int n;                  // live rows
     int row_begin, row_end; // i range
-    int rb_first;           // first 256-row block
-    int ct_per_chunk;       // column tiles per block
+    int rb_first;           // first row block
     int nct;                // column tiles in total = ceil(n / 64)
+    // work decomposition: 1-D grid.  Blocks [0, n_items_a) take `ch_a` column tiles each of row
+    // blocks [rb_first, rb_split); the rest take `ch_b` (smaller) tiles of row blocks >= rb_split.
+    // Big items first, small items last: the tail of the launch is made of short blocks.
+    int n_items_a, chunks_a, ch_a, ctmin_a;
+    int rb_split, chunks_b, ch_b, ctmin_b;
     float u_hi;             // candidate prefilter: u < u_hi
     float u_lo;             // surely-below-threshold bound: u' < u_lo
     uint32_t cut_bits;      // emit when bits(u') <= cut_bits (or not sure)
@@ -75,21 +101,26 @@ struct ScanArgs {
 // ------------------------------------------------------------------------------------------------
 // image construction
 // ------------------------------------------------------------------------------------------------
+// floats per image row: NG spatial chunks, an optional all-zero pad chunk that makes the number of
+// 16-byte chunks odd (rows then start 16 chunk-slots apart modulo the 256-byte LDS bank row), and
+// the time chunk LAST (hm_img_time reads RS - 4).
+__host__ __device__ constexpr int hm_row_floats(int NG) { return 4 * NG + 4 + ((HM_ODD_STRIDE && ((NG + 1) % 2 == 0)) ? 4 : 0); }
+
 __device__ __forceinline__ int hm_pos_in_group(int s) { return ((s & 1) << 1) | ((s >> 1) & 1); }  // 0,2,1,3
 
 __global__ void hm_build_image_kernel(const float* __restrict__ X, int64_t ld, int d, int NG, float* __restrict__ img,
                                       int64_t row_begin, int64_t row_end)
 {
-    const int RS = 4 * NG + 4;
+    const int RS = hm_row_floats(NG);
     const int64_t total = (row_end - row_begin) * RS;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = row_begin + t / RS;
         const int p = (int)(t % RS);
         const int g = p >> 2, q = p & 3;
         float v = 0.0f;
-        if (g == NG) {
+        if (g == RS / 4 - 1) {
             if (q == 0) v = X[row * ld];
-        } else {
+        } else if (g < NG) {
             const int s = 4 * g + (((q & 1) << 1) | (q >> 1));   // inverse of hm_pos_in_group
             if (s < d) v = X[row * ld + 1 + s];
         }
@@ -161,27 +192,37 @@ __device__ __forceinline__ uint32_t hm_wave_incl_scan(uint32_t v, int lane)
 }
 
 template <int NG, int SIGN, int MODE>
-__global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
+__global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanArgs p)
 {
-    constexpr int RS = 4 * NG + 4;                 // floats per image row
+    constexpr int RS = hm_row_floats(NG);          // floats per image row
     constexpr int TILE_FLOATS = HM_COLS_PER_TILE * RS;
-    constexpr int NP = NG + 1;                     // 1 KiB pieces per tile
+    constexpr int NP = NG + 1;                     // k-groups: NG spatial + time
+    constexpr int NPIECE = RS / 4;                 // 1 KiB pieces per 64-row tile (one per 16-byte chunk column)
+    constexpr int TCH = RS / 4 - 1;                // chunk index of the time group
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 * TILE_FLOATS (+ hist)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
 
-    const int rb = p.rb_first + blockIdx.y;
-    int ct0 = blockIdx.x * p.ct_per_chunk;
-    int ct1 = ct0 + p.ct_per_chunk;
-    if (ct0 < 4 * rb) ct0 = 4 * rb;                // tiles left of the diagonal hold no i < j
+    int rb, ct0, ct1;
+    if ((int)blockIdx.x < p.n_items_a) {
+        rb = p.rb_first + (int)blockIdx.x / p.chunks_a;
+        ct0 = p.ctmin_a + ((int)blockIdx.x % p.chunks_a) * p.ch_a;
+        ct1 = ct0 + p.ch_a;
+    } else {
+        const int it = (int)blockIdx.x - p.n_items_a;
+        rb = p.rb_split + it / p.chunks_b;
+        ct0 = p.ctmin_b + (it % p.chunks_b) * p.ch_b;
+        ct1 = ct0 + p.ch_b;
+    }
+    if (ct0 < (rb * HM_ROWS_PER_BLOCK) / HM_COLS_PER_TILE) ct0 = (rb * HM_ROWS_PER_BLOCK) / HM_COLS_PER_TILE;   // left of the diagonal: no i < j
     if (ct1 > p.nct) ct1 = p.nct;
     if (ct0 >= ct1) return;
 
-    const int i0w = rb * HM_ROWS_PER_BLOCK + wave * 64;          // first stationary row of this wave
-    const bool wave_active = (i0w < p.row_end) && (i0w + 63 >= p.row_begin) && (i0w < p.n);
-    const bool rows_full = (i0w >= p.row_begin) && (i0w + 63 < p.row_end);
+    const int i0w = rb * HM_ROWS_PER_BLOCK + wave * HM_WAVE_ROWS;   // first stationary row of this wave
+    const bool wave_active = (i0w < p.row_end) && (i0w + HM_WAVE_ROWS - 1 >= p.row_begin) && (i0w < p.n);
+    const bool rows_full = (i0w >= p.row_begin) && (i0w + HM_WAVE_ROWS - 1 < p.row_end);
 
     // The MFMA result u_f (plain fmaf chain) and the canonical u_c (torch reduction order) are two
     // roundings of the same exact form; |u_f - u_c| <= delta (gamma_n bound on both, |terms| <= rmax2).
@@ -200,12 +241,12 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
     }
 
     // ---- stationary A fragments: lane (r, h) keeps its operands of every k-step in registers ----
-    float2 a[2][NP];
+    float2 a[HM_TM][NP];
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+    for (int tm = 0; tm < HM_TM; ++tm) {
         const float* src = p.img + (int64_t)(i0w + 32 * tm + r) * RS + 2 * h;
 #pragma unroll
-        for (int g = 0; g < NP; ++g) a[tm][g] = *reinterpret_cast<const float2*>(src + 4 * g);
+        for (int g = 0; g < NP; ++g) a[tm][g] = *reinterpret_cast<const float2*>(src + 4 * (g < NG ? g : TCH));
         a[tm][NG].x = -a[tm][NG].x;                // time step: acc = S - x0*y0 = -M
     }
 
@@ -214,22 +255,21 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
     // the tile being computed; the matching wait is the explicit vmcnt(0) in front of the barrier
     // that ends each iteration (cdna_hip_programming.md section 5.7, LDS-DMA recipe).
     const uint32_t lds_base = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)smem);
-    auto dma_tile = [&](int ct, int buf) {
-        const char* gsrc = reinterpret_cast<const char*>(p.img + (int64_t)ct * TILE_FLOATS) + lane * 16;
-        const uint32_t ldst = lds_base + (uint32_t)buf * (uint32_t)(TILE_FLOATS * 4);
-#pragma unroll
-        for (int q0 = 0; q0 < NP; q0 += 4) {
-            const int q = q0 + wave;
-            if (q < NP) {
-                const char* src = gsrc + q * 1024;
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(ldst + (uint32_t)q * 1024u);
-                uint32_t keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep)
-                             : "v"(src), "s"(dst)
-                             : "memory");
-            }
+    auto dma_piece = [&](int ct, int buf, int q) {          // q: wave-uniform piece index
+        if (q < NPIECE) {
+            const char* src = reinterpret_cast<const char*>(p.img + (int64_t)ct * TILE_FLOATS) + lane * 16 + q * 1024;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * (uint32_t)(TILE_FLOATS * 4) + (uint32_t)q * 1024u);
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "s"(dst)
+                         : "memory");
         }
+    };
+    constexpr int PPW = (NPIECE + 3) / 4;                   // pieces per wave
+    auto dma_tile = [&](int ct, int buf) {
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) dma_piece(ct, buf, t * 4 + wave);
     };
 
     // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
@@ -248,42 +288,72 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
     int buf = 0;
 
     for (int ct = ct0; ct < ct1; ct += ct_step, buf ^= 1) {
-        if (ct + ct_step < ct1) dma_tile(ct + ct_step, buf ^ 1);
+        const bool has_next = (ct + ct_step < ct1);          // block-uniform
 
         const int j0 = ct * HM_COLS_PER_TILE;
         const bool compute = wave_active && (j0 + 63 > i0w);
 
+        if (!HM_DMA_INTERLEAVE || !compute || NP - 1 < PPW) {
+            if (has_next) dma_tile(ct + ct_step, buf ^ 1);
+        }
         if (compute) {
-            f32x16 acc[2][2];
+            unsigned long long gk = ~0ull;
+            if (MODE == HM_MODE_ARGMIN)
+                gk = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f32x16 acc[HM_TM][2];
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < HM_TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.0f;
 
+            // B fragments (optionally fetched one k-group ahead of the MFMAs that consume them)
             const float* bt = smem + buf * TILE_FLOATS + r * RS + 2 * h;
+#if HM_PREFETCH_B
+            float2 b0 = *reinterpret_cast<const float2*>(bt);
+            float2 b1 = *reinterpret_cast<const float2*>(bt + 32 * RS);
+#endif
 #pragma unroll
             for (int g = 0; g < NP; ++g) {
-                const float2 b0 = *reinterpret_cast<const float2*>(bt + 4 * g);
-                const float2 b1 = *reinterpret_cast<const float2*>(bt + 32 * RS + 4 * g);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][g].x, b0.x, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][g].x, b1.x, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][g].x, b0.x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][g].x, b1.x, acc[1][1], 0, 0, 0);
-                if (g < NG) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][g].y, b0.y, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][g].y, b1.y, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][g].y, b0.y, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][g].y, b1.y, acc[1][1], 0, 0, 0);
+#if HM_PREFETCH_B
+                float2 n0 = b0, n1 = b1;
+                if (g + 1 < NP) {
+                    n0 = *reinterpret_cast<const float2*>(bt + 4 * (g + 1 < NG ? g + 1 : TCH));
+                    n1 = *reinterpret_cast<const float2*>(bt + 32 * RS + 4 * (g + 1 < NG ? g + 1 : TCH));
                 }
+#else
+                const float2 b0 = *reinterpret_cast<const float2*>(bt + 4 * (g < NG ? g : TCH));
+                const float2 b1 = *reinterpret_cast<const float2*>(bt + 32 * RS + 4 * (g < NG ? g : TCH));
+#endif
+#if HM_DMA_INTERLEAVE
+                // next tile's LDS-DMA pieces are issued between the MFMAs of the first k-groups: their
+                // issue slots hide behind the 64-cycle matrix instructions
+                if (NP - 1 >= PPW && g >= 1 && g - 1 < PPW && has_next) dma_piece(ct + ct_step, buf ^ 1, (g - 1) * 4 + wave);
+#endif
+#pragma unroll
+                for (int tm = 0; tm < HM_TM; ++tm) {
+                    acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].x, b0.x, acc[tm][0], 0, 0, 0);
+                    acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].x, b1.x, acc[tm][1], 0, 0, 0);
+                }
+                if (g < NG) {
+#pragma unroll
+                    for (int tm = 0; tm < HM_TM; ++tm) {
+                        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].y, b0.y, acc[tm][0], 0, 0, 0);
+                        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].y, b1.y, acc[tm][1], 0, 0, 0);
+                    }
+                }
+#if HM_PREFETCH_B
+                b0 = n0;
+                b1 = n1;
+#endif
             }
             // acc = S - x0*y0 = -M.  u = -M (reference sign) = acc;  u = +M (lorentz) = -acc.
 
             // ---- fast check: the lane's most promising u against the current bound ----
             float ext = acc[0][0][0];
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < HM_TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -294,10 +364,9 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
             float bound_f = pre_f;
             uint32_t best_bits = 0xffffffffu, best_low = 0xffffffffu;
             if (MODE == HM_MODE_ARGMIN) {
-                // running best key over everything published so far; an entry can only order before it
-                // if its u_f is within 2*delta (+ a few ulps of acosh wiggle) of the best u_f
-                const unsigned long long gk =
-                    __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // running best key over everything published so far (loaded before the MFMA loop so
+                // that its latency is hidden); an entry can only order before it if its u_f is within
+                // 2*delta (+ a few ulps of acosh wiggle) of the best u_f
                 best_bits = (uint32_t)(gk >> 32);
                 best_low = (uint32_t)gk;
                 if (best_bits != 0xffffffffu) {
@@ -307,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
             }
 
             if (__ballot(ext_u < bound_f) != 0ull) {
-                const bool full = rows_full && (j0 > i0w + 63) && (j0 + 63 < p.n);
+                const bool full = rows_full && (j0 > i0w + HM_WAVE_ROWS - 1) && (j0 + 63 < p.n);
                 // -------- slow path: per-element predicates, evaluated twice (count, then write).
                 // The second evaluation runs on laundered copies of the bounds so that the compiler
                 // does not keep 64 predicates alive across the wave scan (that spills).
@@ -357,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
                     ++slot;
                 };
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
+                for (int tm = 0; tm < HM_TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -374,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void hm_scan_kernel(const ScanArgs p)
                         slot = base + incl - n_emit;
                         asm volatile("" : "+v"(bnd), "+v"(cutv));      // opaque: no CSE with the count pass
 #pragma unroll
-                        for (int tm = 0; tm < 2; ++tm)
+                        for (int tm = 0; tm < HM_TM; ++tm)
 #pragma unroll
                             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -417,16 +486,35 @@ __device__ __forceinline__ bool hm_key_less(uint32_t a0, uint32_t a1, uint32_t a
     return a2 < b2;
 }
 
-// one block: canonical distance of every entry, threshold, lexicographic min of (dbits, i, j)
-__global__ __launch_bounds__(1024) void hm_post_argmin_kernel(const uint4* __restrict__ ent, const uint32_t* __restrict__ ctr,
-                                                              uint32_t cap, const float* __restrict__ img, int RS, int d,
-                                                              int sign_mode, float sqrt_c, float thr, ArgminRec* out)
+// canonical distance of every entry, threshold, lexicographic min of (dbits, i, j).
+// Stage 1: HM_ARGMIN_BLOCKS blocks, one partial record each; stage 2: one block over the partials.
+#define HM_ARGMIN_BLOCKS 64
+struct ArgminPart { uint32_t dbits, i, j, pad; };
+
+__device__ __forceinline__ void hm_block_min_key(uint32_t& b0, uint32_t& b1, uint32_t& b2, uint32_t* s0, uint32_t* s1, uint32_t* s2)
 {
-    __shared__ uint32_t s0[1024], s1[1024], s2[1024];
+    const int t = threadIdx.x;
+    s0[t] = b0; s1[t] = b1; s2[t] = b2;
+    __syncthreads();
+    for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+        if (t < off) {
+            const int o = t + off;
+            if (hm_key_less(s0[o], s1[o], s2[o], s0[t], s1[t], s2[t])) { s0[t] = s0[o]; s1[t] = s1[o]; s2[t] = s2[o]; }
+        }
+        __syncthreads();
+    }
+    b0 = s0[0]; b1 = s1[0]; b2 = s2[0];
+}
+
+__global__ __launch_bounds__(256) void hm_post_argmin_kernel(const uint4* __restrict__ ent, const uint32_t* __restrict__ ctr,
+                                                             uint32_t cap, const float* __restrict__ img, int RS, int d,
+                                                             int sign_mode, float sqrt_c, float thr, ArgminPart* __restrict__ parts)
+{
+    __shared__ uint32_t s0[256], s1[256], s2[256];
     uint32_t m = ctr[0];
     if (m > cap) m = cap;
     uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
-    for (uint32_t t = threadIdx.x; t < m; t += 1024) {
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < m; t += gridDim.x * 256) {
         const uint4 en = ent[t];
         const float dd = hm::dist_from_u(hm_img_u(img, RS, d, en.y, en.z, sign_mode), sqrt_c);
         if (dd < thr) {
@@ -434,20 +522,18 @@ __global__ __launch_bounds__(1024) void hm_post_argmin_kernel(const uint4* __res
             if (hm_key_less(db, en.y, en.z, b0, b1, b2)) { b0 = db; b1 = en.y; b2 = en.z; }
         }
     }
-    s0[threadIdx.x] = b0; s1[threadIdx.x] = b1; s2[threadIdx.x] = b2;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            const int o = threadIdx.x + off;
-            if (hm_key_less(s0[o], s1[o], s2[o], s0[threadIdx.x], s1[threadIdx.x], s2[threadIdx.x])) {
-                s0[threadIdx.x] = s0[o]; s1[threadIdx.x] = s1[o]; s2[threadIdx.x] = s2[o];
-            }
-        }
-        __syncthreads();
-    }
+    hm_block_min_key(b0, b1, b2, s0, s1, s2);
+    if (threadIdx.x == 0) { parts[blockIdx.x].dbits = b0; parts[blockIdx.x].i = b1; parts[blockIdx.x].j = b2; parts[blockIdx.x].pad = 0; }
+}
+
+__global__ __launch_bounds__(HM_ARGMIN_BLOCKS) void hm_post_argmin_final_kernel(const ArgminPart* __restrict__ parts, ArgminRec* out)
+{
+    __shared__ uint32_t s0[HM_ARGMIN_BLOCKS], s1[HM_ARGMIN_BLOCKS], s2[HM_ARGMIN_BLOCKS];
+    uint32_t b0 = parts[threadIdx.x].dbits, b1 = parts[threadIdx.x].i, b2 = parts[threadIdx.x].j;
+    hm_block_min_key(b0, b1, b2, s0, s1, s2);
     if (threadIdx.x == 0) {
-        out->found = (s1[0] != 0xffffffffu) ? 1u : 0u;
-        out->dbits = s0[0]; out->i = s1[0]; out->j = s2[0];
+        out->found = (b1 != 0xffffffffu) ? 1u : 0u;
+        out->dbits = b0; out->i = b1; out->j = b2;
     }
 }
 
@@ -646,7 +732,7 @@ __global__ void hm_merge_append_kernel(float* __restrict__ img, int RS, int d, i
                      [&](int k, float v) {
                          xr[k] = v;
                          r2 = __builtin_fmaf(v, v, r2);
-                         if (k == 0) ir[4 * NG] = v;
+                         if (k == 0) ir[RS - 4] = v;
                          else ir[4 * ((k - 1) >> 2) + hm_pos_in_group((k - 1) & 3)] = v;
                      },
                      scratch);
@@ -758,6 +844,7 @@ struct hm_engine {
     uint32_t* d_rmax2 = nullptr;          // float bits of the largest squared row norm
     unsigned long long* d_ctr64 = nullptr; // 2 x u64
     ArgminRec* d_rec = nullptr;
+    ArgminPart* d_parts = nullptr;
     uint32_t* d_hist = nullptr;           // HM_DIGIT_BINS
     HostCtl* h = nullptr;                 // pinned
     uint4* h_sorted = nullptr;            // pinned, sorted_cap entries
@@ -830,7 +917,7 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     e->d1 = d1;
     e->d = d1 - 1;
     e->NG = hm_pick_ng(e->d);
-    e->RS = 4 * e->NG + 4;
+    e->RS = hm_row_floats(e->NG);
     e->sign_mode = sign_mode;
     e->rows_alloc = (max_rows + HM_ROWS_PER_BLOCK - 1) / HM_ROWS_PER_BLOCK * HM_ROWS_PER_BLOCK + HM_ROWS_PER_BLOCK;
     e->ent_cap = 1u << 24;
@@ -846,6 +933,7 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     HM_HIP(hipMemset(e->d_rmax2, 0, sizeof(uint32_t)));
     HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 2));
     HM_HIP(hipMalloc(&e->d_rec, sizeof(ArgminRec)));
+    HM_HIP(hipMalloc(&e->d_parts, sizeof(ArgminPart) * HM_ARGMIN_BLOCKS));
     HM_HIP(hipMalloc(&e->d_hist, sizeof(uint32_t) * HM_DIGIT_BINS));
     HM_HIP(hipHostMalloc(&e->h, sizeof(HostCtl), hipHostMallocDefault));
     HM_HIP(hipHostMalloc(&e->h_sorted, sizeof(uint4) * (size_t)e->sorted_cap, hipHostMallocDefault));
@@ -859,7 +947,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
 {
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
-    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2};
+    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts};
     for (void* q : dev_ptrs) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);
     if (e->h_sorted) (void)hipHostFree(e->h_sorted);
@@ -949,7 +1037,7 @@ static Bounds hm_bounds(float thr, float c)
 template <int NG, int SIGN, int MODE>
 static hipError_t hm_launch_scan_t(const ScanArgs& a, dim3 grid, hipStream_t s)
 {
-    size_t lds = sizeof(float) * 2 * HM_COLS_PER_TILE * (4 * NG + 4);
+    size_t lds = sizeof(float) * 2 * HM_COLS_PER_TILE * hm_row_floats(NG);
     if (MODE == HM_MODE_HIST) lds += sizeof(uint32_t) * HM_HIST_BINS;
     static bool attr_set = false;    // per instantiation
     if (!attr_set && lds > 48 * 1024) {
@@ -1021,13 +1109,35 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     a.hist = e->d_hist;
     a.sample_stride = 1;
     a.rmax2_bits = e->d_rmax2;
-    const int nrb = (int)((row_end - 1) / HM_ROWS_PER_BLOCK) - a.rb_first + 1;
-    // column tiles per block: keep >= ~2048 blocks in flight for large tables, amortise the
-    // stationary-row load for small ones
-    int ch = 32;
+    const int rb_last = (int)((row_end - 1) / HM_ROWS_PER_BLOCK);
+    const int nrb = rb_last - a.rb_first + 1;
+    const int tiles_per_rb = HM_ROWS_PER_BLOCK / HM_COLS_PER_TILE;          // diagonal advance per row block
+    // column tiles per block: amortise the stationary-row load, but keep enough blocks in flight
+    int ch = HM_CHUNK_TILES;
     while (ch > 4 && (int64_t)nrb * ((a.nct + ch - 1) / ch) < 1024) ch >>= 1;
-    a.ct_per_chunk = ch;
-    grid = dim3((unsigned)((a.nct + ch - 1) / ch), (unsigned)nrb, 1);
+    // phase B = the last ~HM_TAIL_FRACTION of the work (row blocks near the bottom of the triangle),
+    // cut into chunks a quarter the size
+    a.ctmin_a = a.rb_first * tiles_per_rb;
+    int rb_split = rb_last + 1;
+    int ch_b = ch;
+    if (ch >= 16 && nrb >= 16) {
+        double total = 0.0, acc = 0.0;
+        for (int rb = a.rb_first; rb <= rb_last; ++rb) total += (double)std::max(0, a.nct - rb * tiles_per_rb);
+        for (int rb = rb_last; rb >= a.rb_first; --rb) {
+            acc += (double)std::max(0, a.nct - rb * tiles_per_rb);
+            if (acc >= HM_TAIL_FRACTION * total) { rb_split = rb; break; }
+        }
+        ch_b = ch / 4;
+    }
+    a.ch_a = ch;
+    a.chunks_a = std::max(1, (a.nct - a.ctmin_a + ch - 1) / ch);
+    a.n_items_a = (rb_split - a.rb_first) * a.chunks_a;
+    a.rb_split = rb_split;
+    a.ch_b = ch_b;
+    a.ctmin_b = rb_split * tiles_per_rb;
+    a.chunks_b = std::max(1, (a.nct - a.ctmin_b + ch_b - 1) / ch_b);
+    const int n_items_b = (rb_last + 1 - rb_split) * a.chunks_b;
+    grid = dim3((unsigned)(a.n_items_a + n_items_b), 1, 1);
     return true;
 }
 
@@ -1060,8 +1170,10 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
         HM_HIP(hipEventRecord(e->ev0, s));
         HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s));
         HM_HIP(hipEventRecord(e->ev1, s));
-        hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(1), dim3(1024), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img, e->RS, e->d,
-                           e->sign_mode, sqrt_c, thr, e->d_rec);
+        hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(HM_ARGMIN_BLOCKS), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img,
+                           e->RS, e->d, e->sign_mode, sqrt_c, thr, e->d_parts);
+        HM_HIP(hipGetLastError());
+        hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec);
         HM_HIP(hipGetLastError());
         HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
         HM_HIP(hipMemcpyAsync(e->h->ctr, e->d_ctr, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, s));
@@ -1207,7 +1319,7 @@ static int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row
     uint32_t cut_bits = 0xffffffffu;
     int tie_imax = 0x7fffffff;
     if (!list_all) {
-        if (whole && e->have_cut && e->last_cut_k >= k && e->last_cut_c == c) {
+        if (whole && e->have_cut && e->last_cut_k >= k && e->last_cut_c == c && e->last_cut_bits > 0x3f800000u) {
             cut_bits = e->last_cut_bits + HM_TIE_SLACK;
         } else {
             int rc = hm_estimate_cut(e, a, grid, 4 * k + 4096, &cut_bits, &tie_imax, s);

@@ -21,7 +21,7 @@ from tqdm import tqdm
 
 from hyptokenizer_amd.embedding.lorentz_model import distance, exp_map, project_to_hyperboloid
 from hyptokenizer_amd.tokenizer.fast_hyperbolic_merge import FastHyperbolicTokenizer
-from hyptokenizer_amd.tokenizer.hyperbolic_merge import HyperbolicTokenizer
+from hyptokenizer_amd.tokenizer.hyperbolic_merge import TQDM_OFF, HyperbolicTokenizer
 
 logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
 logger = logging.getLogger(__name__)
@@ -129,7 +129,7 @@ def train_tokenizer(
         tokenizer.optimize_merges(steps=merge_steps, log_every=log_every)
     else:
         # reference ``:236-286``: own loop with callback, target size and x1.05 every 1000 steps
-        bar = tqdm(range(merge_steps), desc="Optimizing merges")
+        bar = tqdm(range(merge_steps), desc="Optimizing merges", disable=TQDM_OFF)
         for step in bar:
             log_callback(step, tokenizer)
             if target_vocab_size is not None and len(tokenizer.vocab) >= target_vocab_size:

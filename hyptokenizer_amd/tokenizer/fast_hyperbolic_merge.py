@@ -23,7 +23,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .hyperbolic_merge import HyperbolicTokenizer
+from .hyperbolic_merge import TQDM_OFF, HyperbolicTokenizer
 
 FAISS_AVAILABLE = False     # replaced entirely by the exact GPU search
 
@@ -221,7 +221,7 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         consumption, empty-step handling, x1.1 every 1000 steps)."""
         from tqdm import tqdm
 
-        bar = tqdm(range(steps), desc="Optimizing merges")
+        bar = tqdm(range(steps), desc="Optimizing merges", disable=TQDM_OFF)
         empty_steps = 0
         stats = {"step": [], "vocab_size": [], "min_dist": [], "max_dist": [], "mean_dist": [], "num_candidates": []}
 

@@ -34,6 +34,9 @@ from ..engine import HypMergeUnavailable, MergeEngine, sign_mode_id
 
 logger = logging.getLogger(__name__)
 
+# progress bars: off when TQDM_DISABLE is set, and automatically on a non-TTY stderr (disable=None)
+TQDM_OFF = True if os.environ.get("TQDM_DISABLE") else None
+
 FAISS_AVAILABLE = False            # the HNSW / Flat index path is replaced by the exact GPU search
 TORCH_COMPILE_AVAILABLE = hasattr(torch, "compile")
 USING_COMPILED = False             # no tracing compiler on this path: the kernels are hand-written
@@ -186,7 +189,7 @@ class HyperbolicTokenizer:
         """Greedy merge loop (reference ``:357-412``).  ``parallel_eval`` and ``sample_ratio`` never
         change which pair is merged in the reference (``:381-393``, ``:553-591``) and are accepted
         for compatibility."""
-        bar = tqdm(range(steps), desc="Optimizing merges")
+        bar = tqdm(range(steps), desc="Optimizing merges", disable=TQDM_OFF)
         for step in bar:
             best = self._best_candidate()
             if best is None:
