@@ -51,6 +51,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef HM_TAIL_FRACTION
 #define HM_TAIL_FRACTION 0.15      // share of the work issued last in quarter-size chunks
 #endif
+#ifndef HM_SKIP_EMPTY
+#define HM_SKIP_EMPTY 0            // triangular item numbering (no block left of the diagonal): no gain measured
+#endif
+#ifndef HM_SWIZZLE_IDENTITY
+#define HM_SWIZZLE_IDENTITY 0      // experiment: swizzle sizing without the mirrored mapping
+#endif
+#ifndef HM_SWIZZLE_EXTRA
+#define HM_SWIZZLE_EXTRA 0         // experiment: extra chunks per row (breaks the XCD alignment)
+#endif
+#ifndef HM_TILE_ROTATE
+#define HM_TILE_ROTATE 1           // per-block rotation of the tile order inside a chunk
+#endif
+#ifndef HM_XCD_SWIZZLE
+#define HM_XCD_SWIZZLE 0           // XCD-aware slot -> chunk order (L2-local but slower: see DESIGN.md section 6)
+#endif
 #ifndef HM_DMA_INTERLEAVE
 #define HM_DMA_INTERLEAVE 1        // issue the next tile's LDS-DMA between MFMAs instead of ahead of them
 #endif
@@ -71,6 +86,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define HM_DIGIT_BINS 4096
 #define HM_RANK_LIMIT 49152        // rank sort is O(M^2): narrow by radix digits above this
 
+// items before local row R when row r owns (chunks - floor(r / m)) items
+__host__ __device__ __forceinline__ int hm_tri_cum(int R, int chunks, int m)
+{
+    const int q = R / m;
+    return R * chunks - (m * (q * (q - 1) / 2) + (R - m * q) * q);
+}
+
 struct ScanArgs {
     const float* img;
     int n;                  // live rows
@@ -82,10 +104,17 @@ struct ScanArgs {
     // Big items first, small items last: the tail of the launch is made of short blocks.
     int n_items_a, chunks_a, ch_a, ctmin_a;
     int rb_split, chunks_b, ch_b, ctmin_b;
+    // XCD-aware slot order (HM_XCD_SWIZZLE): chunks per row block are a multiple of 16 and the
+    // chunk of slot s (= block id modulo chunks) is mirrored inside each group of 16 (slots 8..15 take
+    // chunks 15..8).  Blocks b and b + 8 share an XCD (observed round-robin placement; a speed
+    // assumption only), so every XCD keeps streaming the same <= n/8 partner rows -- they stay in
+    // its 4 MiB L2 -- and the mirrored pairs give every XCD the same share of the triangle.
+    int swizzle;
+    int skip_empty, rows_a, m_a, rows_b, m_b;   // triangular item numbering (no empty blocks)
     float u_hi;             // candidate prefilter: u < u_hi
     float u_lo;             // surely-below-threshold bound: u' < u_lo
     uint32_t cut_bits;      // emit when bits(u') <= cut_bits (or not sure)
-    int tie_imax;           // entries with bits(u') == cut_bits only when i <= tie_imax
+    int tie_imax;           // zero-distance ties are emitted only for rows i <= tie_imax
     int thr_pos;            // thr > 0: u' == 1 gives d == 0, surely a candidate
     uint4* ent;
     uint32_t ent_cap;
@@ -206,14 +235,35 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
     const int r = lane & 31, h = lane >> 5;
 
     int rb, ct0, ct1;
-    if ((int)blockIdx.x < p.n_items_a) {
+    auto slot_to_chunk = [&](int slot) {
+        if (!p.swizzle || HM_SWIZZLE_IDENTITY) return slot;
+        const int q = slot & 15;
+        return (slot & ~15) | (q < 8 ? q : 23 - q);
+    };
+    if (p.skip_empty) {
+        // triangular item numbering: local row r of a phase owns chunks floor(r / m) .. chunks - 1
+        // (m = rows per chunk step of the diagonal), so no block is launched left of the diagonal
+        const bool ph_a = (int)blockIdx.x < p.n_items_a;
+        const int it = ph_a ? (int)blockIdx.x : (int)blockIdx.x - p.n_items_a;
+        const int chunks = ph_a ? p.chunks_a : p.chunks_b;
+        const int m = ph_a ? p.m_a : p.m_b;
+        int lo = 0, hi = (ph_a ? p.rows_a : p.rows_b) - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (hm_tri_cum(mid, chunks, m) <= it) lo = mid; else hi = mid - 1;
+        }
+        const int c = lo / m + (it - hm_tri_cum(lo, chunks, m));
+        rb = (ph_a ? p.rb_first : p.rb_split) + lo;
+        ct0 = (ph_a ? p.ctmin_a : p.ctmin_b) + c * (ph_a ? p.ch_a : p.ch_b);
+        ct1 = ct0 + (ph_a ? p.ch_a : p.ch_b);
+    } else if ((int)blockIdx.x < p.n_items_a) {
         rb = p.rb_first + (int)blockIdx.x / p.chunks_a;
-        ct0 = p.ctmin_a + ((int)blockIdx.x % p.chunks_a) * p.ch_a;
+        ct0 = p.ctmin_a + slot_to_chunk((int)blockIdx.x % p.chunks_a) * p.ch_a;
         ct1 = ct0 + p.ch_a;
     } else {
         const int it = (int)blockIdx.x - p.n_items_a;
         rb = p.rb_split + it / p.chunks_b;
-        ct0 = p.ctmin_b + (it % p.chunks_b) * p.ch_b;
+        ct0 = p.ctmin_b + slot_to_chunk(it % p.chunks_b) * p.ch_b;
         ct1 = ct0 + p.ch_b;
     }
     if (ct0 < (rb * HM_ROWS_PER_BLOCK) / HM_COLS_PER_TILE) ct0 = (rb * HM_ROWS_PER_BLOCK) / HM_COLS_PER_TILE;   // left of the diagonal: no i < j
@@ -280,21 +330,30 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
         if (ct0 >= ct1) return;
     }
 
-    dma_tile(ct0, 0);
+    // Blocks that share a column chunk (and, with the XCD-aware slot order, an L2) would otherwise
+    // walk the same tiles in lockstep and queue on the same cache lines: each block starts at its
+    // own tile of the chunk and wraps around.
+    const int ntile = (ct1 - ct0 + ct_step - 1) / ct_step;
+    const int rot = (HM_TILE_ROTATE && p.swizzle) ? (int)((unsigned)(rb * 5) % (unsigned)ntile) : 0;
+    auto tile_at = [&](int t) { int q = t + rot; if (q >= ntile) q -= ntile; return ct0 + q * ct_step; };
+
+    dma_tile(tile_at(0), 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     uint32_t sure_total = 0;         // per-lane partial of the sure count
     int buf = 0;
 
-    for (int ct = ct0; ct < ct1; ct += ct_step, buf ^= 1) {
-        const bool has_next = (ct + ct_step < ct1);          // block-uniform
+    for (int t = 0; t < ntile; ++t, buf ^= 1) {
+        const int ct = tile_at(t);
+        const bool has_next = (t + 1 < ntile);               // block-uniform
+        const int ct_next = has_next ? tile_at(t + 1) : ct;
 
         const int j0 = ct * HM_COLS_PER_TILE;
         const bool compute = wave_active && (j0 + 63 > i0w);
 
         if (!HM_DMA_INTERLEAVE || !compute || NP - 1 < PPW) {
-            if (has_next) dma_tile(ct + ct_step, buf ^ 1);
+            if (has_next) dma_tile(ct_next, buf ^ 1);
         }
         if (compute) {
             unsigned long long gk = ~0ull;
@@ -329,7 +388,7 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
 #if HM_DMA_INTERLEAVE
                 // next tile's LDS-DMA pieces are issued between the MFMAs of the first k-groups: their
                 // issue slots hide behind the 64-cycle matrix instructions
-                if (NP - 1 >= PPW && g >= 1 && g - 1 < PPW && has_next) dma_piece(ct + ct_step, buf ^ 1, (g - 1) * 4 + wave);
+                if (NP - 1 >= PPW && g >= 1 && g - 1 < PPW && has_next) dma_piece(ct_next, buf ^ 1, (g - 1) * 4 + wave);
 #endif
 #pragma unroll
                 for (int tm = 0; tm < HM_TM; ++tm) {
@@ -715,28 +774,36 @@ __global__ void hm_midpoint_kernel(const float* __restrict__ img, int RS, int d,
     hm_midpoint_core(d, W[t], c, sign_mode, gx, gy, [&](int k, float v) { o[k] = v; }, scratch);
 }
 
-// fused merge: midpoint of image rows (i, j) -> table row and image row `new_row`
-__global__ void hm_merge_append_kernel(float* __restrict__ img, int RS, int d, int NG, int32_t i, int32_t j, float w, float c,
-                                       int sign_mode, float* __restrict__ X, int64_t ld, int64_t new_row,
-                                       uint32_t* __restrict__ rmax2_bits)
+// fused merge: midpoint of image rows (i, j) -> table row and image row `new_row`.
+// One wave: the two rows are staged into LDS with coalesced loads, lane 0 runs the (inherently
+// sequential) canonical arithmetic on LDS operands, all lanes write the result.
+__global__ __launch_bounds__(64) void hm_merge_append_kernel(float* __restrict__ img, int RS, int d, int NG, int32_t i, int32_t j,
+                                                             float w, float c, int sign_mode, float* __restrict__ X, int64_t ld,
+                                                             int64_t new_row, uint32_t* __restrict__ rmax2_bits)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float scratch[HM_MAX_D1];
+    __shared__ float sx[HM_MAX_D1], sy[HM_MAX_D1], sv[HM_MAX_D1], so[HM_MAX_D1];
+    const int lane = threadIdx.x;
     const int64_t ri = i, rj = j;
-    auto gx = [&](int k) { return k == 0 ? hm_img_time(img, RS, ri) : hm_img_spatial(img, RS, ri, k - 1); };
-    auto gy = [&](int k) { return k == 0 ? hm_img_time(img, RS, rj) : hm_img_spatial(img, RS, rj, k - 1); };
+    for (int k = lane; k <= d; k += 64) {
+        sx[k] = k == 0 ? hm_img_time(img, RS, ri) : hm_img_spatial(img, RS, ri, k - 1);
+        sy[k] = k == 0 ? hm_img_time(img, RS, rj) : hm_img_spatial(img, RS, rj, k - 1);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float r2 = 0.0f;
+        hm_midpoint_core(d, w, c, sign_mode, [&](int k) { return sx[k]; }, [&](int k) { return sy[k]; },
+                         [&](int k, float v) { so[k] = v; r2 = __builtin_fmaf(v, v, r2); }, sv);
+        if (r2 < 3.0e38f && r2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(r2));
+    }
+    __syncthreads();
     float* xr = X + new_row * ld;
     float* ir = img + new_row * RS;
-    float r2 = 0.0f;
-    hm_midpoint_core(d, w, c, sign_mode, gx, gy,
-                     [&](int k, float v) {
-                         xr[k] = v;
-                         r2 = __builtin_fmaf(v, v, r2);
-                         if (k == 0) ir[RS - 4] = v;
-                         else ir[4 * ((k - 1) >> 2) + hm_pos_in_group((k - 1) & 3)] = v;
-                     },
-                     scratch);
-    if (r2 < 3.0e38f && r2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(r2));
+    for (int k = lane; k <= d; k += 64) {
+        const float v = so[k];
+        xr[k] = v;
+        if (k == 0) ir[RS - 4] = v;
+        else ir[4 * ((k - 1) >> 2) + hm_pos_in_group((k - 1) & 3)] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1131,13 +1198,39 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     }
     a.ch_a = ch;
     a.chunks_a = std::max(1, (a.nct - a.ctmin_a + ch - 1) / ch);
-    a.n_items_a = (rb_split - a.rb_first) * a.chunks_a;
     a.rb_split = rb_split;
     a.ch_b = ch_b;
     a.ctmin_b = rb_split * tiles_per_rb;
     a.chunks_b = std::max(1, (a.nct - a.ctmin_b + ch_b - 1) / ch_b);
-    const int n_items_b = (rb_last + 1 - rb_split) * a.chunks_b;
-    grid = dim3((unsigned)(a.n_items_a + n_items_b), 1, 1);
+    a.swizzle = 0;
+#if HM_XCD_SWIZZLE
+    if (a.chunks_a >= 12) {
+        // round the chunk counts to multiples of 16 and re-derive the chunk widths
+        a.chunks_a = (a.chunks_a + 15) / 16 * 16 + HM_SWIZZLE_EXTRA;
+        a.ch_a = (a.nct - a.ctmin_a + a.chunks_a - 1) / a.chunks_a;
+        const int wb = a.nct - a.ctmin_b;
+        if (rb_split <= rb_last && wb > 0) {
+            a.chunks_b = std::max(16, (a.chunks_b + 15) / 16 * 16);
+            a.ch_b = std::max(1, (wb + a.chunks_b - 1) / a.chunks_b);
+        }
+        a.swizzle = 1;
+    }
+#endif
+    a.n_items_a = (rb_split - a.rb_first) * a.chunks_a;
+    int n_items_b = (rb_last + 1 - rb_split) * a.chunks_b;
+    a.skip_empty = 0;
+#if HM_SKIP_EMPTY
+    if (!a.swizzle && a.ch_a % tiles_per_rb == 0 && a.ch_b % tiles_per_rb == 0) {
+        a.skip_empty = 1;
+        a.rows_a = rb_split - a.rb_first;
+        a.m_a = a.ch_a / tiles_per_rb;
+        a.rows_b = rb_last + 1 - rb_split;
+        a.m_b = a.ch_b / tiles_per_rb;
+        a.n_items_a = a.rows_a > 0 ? hm_tri_cum(a.rows_a, a.chunks_a, a.m_a) : 0;
+        n_items_b = a.rows_b > 0 ? hm_tri_cum(a.rows_b, a.chunks_b, a.m_b) : 0;
+    }
+#endif
+    grid = dim3((unsigned)std::max(1, a.n_items_a + n_items_b), 1, 1);
     return true;
 }
 

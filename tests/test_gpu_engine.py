@@ -144,3 +144,23 @@ def test_merge_loop_sequence_bit_exact(oracle, mode):
         assert np.array_equal(_bits(table[n].cpu().numpy()), _bits(Xo[n])), step
         n += 1
         assert eng.n == n
+
+
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_banded_decomposition_matches_oracle(oracle, mode):
+    """large enough for the XCD-banded / two-phase work decomposition (n >= 4096): counts, ordered
+    lists and row-range searches against the oracle"""
+    n, d = 6200, 20
+    X = lorentz_table(n, d, seed=5, scale=0.05).numpy()
+    eng, _ = _engine(torch.from_numpy(X), mode)
+    thr = 0.2 if mode == "lorentz" else 0.1
+    for (r0, r1, k) in [(0, -1, 5000), (0, -1, 1), (1000, 5000, 3000), (6000, 6200, 50), (0, 130, 400)]:
+        rr1 = n if r1 < 0 else r1
+        gd, gi, gj, gc = eng.topk(1.0, thr, k, r0, r1)
+        od, oi, oj, oc = oracle.pairwise_topk(X, n, 1.0, thr, MODES[mode], k, r0, rr1, fast=True)
+        assert gc == oc, (r0, r1, gc, oc)
+        assert np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(_bits(gd), _bits(od)), (r0, r1)
+        a = eng.argmin(1.0, thr, r0, r1)
+        assert (a is None) == (oc == 0)
+        if a:
+            assert (a[1], a[2]) == (int(oi[0]), int(oj[0]))
