@@ -81,6 +81,22 @@ def cpu_baseline(X: np.ndarray, device, budget_s: float = 12.0) -> dict:
     }
 
 
+def traffic_from_profiles():
+    """Fabric-side bytes per scan launch from the committed PMC pass (profiles/*_pmc_scan_kernel.json:
+    FETCH_SIZE x 1024 x 2 on gfx950 + WRITE_SIZE x 1024, MI355X_MICROARCH.md HBM section).  PMC
+    counters cannot be collected from inside the timed run; same kernel, same size."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_scan_kernel.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            dd = json.load(f)["derived"]
+        return dd["fetch_bytes_per_launch_corrected"] + dd["write_bytes_per_launch"], os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +180,7 @@ def main() -> None:
         avg_ms = sum(p[0] for p in per_rank) / max(launches, 1.0)           # mean launch duration
         flops_per_launch = 2.0 * (D + 1) * sum(p[1] for p in per_rank) / max(launches, 1.0)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic, traffic_src = traffic_from_profiles() if world == 1 else (None, None)
         n_mid = V + args.warmup + args.steps / 2.0
         scan_ms_per_step = max(p[0] / max(p[2], 1.0) for p in per_rank)     # slowest rank's scan per step
         out = {
@@ -184,7 +201,10 @@ def main() -> None:
                        "vocab": V, "dim": D, "merge_threshold": THR, "parallelism": f"rows sharded over {world} rank(s)"},
             "pairwise_dist_GBps_effective": (n_mid * n_mid * 4.0) / (scan_ms_per_step * 1e-3) / 1e9,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_note": ("bytes per launch past the XCD L2s (FETCH_SIZE corrected x2 + WRITE_SIZE) from "
+                                          f"profiles/{traffic_src}; they are served by the Infinity Cache (the scan image "
+                                          "is 21.6 MB), compulsory bytes = the image once") if traffic else None,
                          "kernel": "hm_scan_kernel<25,1,ARGMIN>", "avg_launch_ms": avg_ms,
                          "flops_per_launch": flops_per_launch, "launches": launches},
             "fast_path": fast,

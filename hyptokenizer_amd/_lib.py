@@ -23,7 +23,7 @@ SIGN_REFERENCE, SIGN_LORENTZ = 0, 1
 #: every symbol include/hypmerge.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = (
     "hm_abi_version", "hm_last_error", "hm_engine_create", "hm_engine_destroy", "hm_set_table",
-    "hm_update_rows", "hm_rows", "hm_pairwise_argmin", "hm_pairwise_topk", "hm_pairwise_candidates",
+    "hm_update_rows", "hm_rows", "hm_pairwise_argmin", "hm_pairwise_argmin_dev", "hm_pairwise_topk", "hm_pairwise_candidates",
     "hm_row_vs_all", "hm_pair_distance", "hm_midpoint_batch", "hm_merge_append", "hm_batch_distance",
     "hm_rows_minkowski", "hm_rows_distance", "hm_rows_log_map", "hm_rows_exp_map", "hm_rows_project",
     "hm_last_scan_stats", "hm_scan_totals",
@@ -72,6 +72,7 @@ def load() -> C.CDLL:
     L.hm_rows.restype = i64
     L.hm_rows.argtypes = [vp]
     L.hm_pairwise_argmin.argtypes = [vp, f32, f32, i64, i64, pf32, pi32, pi32, pi32, vp]
+    L.hm_pairwise_argmin_dev.argtypes = [vp, f32, f32, i64, i64, vp, vp]
     L.hm_pairwise_topk.argtypes = [vp, f32, f32, i64, i64, i64, vp, vp, vp, pi64, pi64, vp]
     L.hm_pairwise_candidates.argtypes = [vp, f32, f32, i64, i64, i64, vp, vp, vp, pi64, vp]
     L.hm_row_vs_all.argtypes = [vp, i64, i64, f32, vp, vp]

@@ -585,13 +585,15 @@ __global__ __launch_bounds__(256) void hm_post_argmin_kernel(const uint4* __rest
     if (threadIdx.x == 0) { parts[blockIdx.x].dbits = b0; parts[blockIdx.x].i = b1; parts[blockIdx.x].j = b2; parts[blockIdx.x].pad = 0; }
 }
 
-__global__ __launch_bounds__(HM_ARGMIN_BLOCKS) void hm_post_argmin_final_kernel(const ArgminPart* __restrict__ parts, ArgminRec* out)
+__global__ __launch_bounds__(HM_ARGMIN_BLOCKS) void hm_post_argmin_final_kernel(const ArgminPart* __restrict__ parts, ArgminRec* out,
+                                                                                const uint32_t* __restrict__ ctr, uint32_t cap)
 {
     __shared__ uint32_t s0[HM_ARGMIN_BLOCKS], s1[HM_ARGMIN_BLOCKS], s2[HM_ARGMIN_BLOCKS];
     uint32_t b0 = parts[threadIdx.x].dbits, b1 = parts[threadIdx.x].i, b2 = parts[threadIdx.x].j;
     hm_block_min_key(b0, b1, b2, s0, s1, s2);
     if (threadIdx.x == 0) {
-        out->found = (b1 != 0xffffffffu) ? 1u : 0u;
+        // found = 2: the emission buffer overflowed, the record is not final (caller reruns bounded)
+        out->found = ctr[0] > cap ? 2u : ((b1 != 0xffffffffu) ? 1u : 0u);
         out->dbits = b0; out->i = b1; out->j = b2;
     }
 }
@@ -926,6 +928,8 @@ struct hm_engine {
     float last_scan_ms = 0.f;
     int64_t last_pairs = 0, last_emitted = 0;
     int last_passes = 0;
+    bool pending_timing = false;   // ev0/ev1 recorded by an asynchronous call, not read yet
+    int64_t pending_pairs = 0;
     double tot_scan_ms = 0.0;
     int64_t tot_pairs = 0, tot_launches = 0;
     std::string err;
@@ -1241,6 +1245,48 @@ static int64_t hm_pairs_in_range(int64_t n, int64_t r0, int64_t r1)
     return cnt * (n - 1) - (r0 + r1 - 1) * cnt / 2;
 }
 
+static void hm_flush_pending_timing(hm_engine* e)
+{
+    if (!e->pending_timing) return;
+    float ms = 0.f;
+    if (hipEventSynchronize(e->ev1) == hipSuccess && hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) {
+        e->last_scan_ms = ms; e->last_pairs = e->pending_pairs; e->last_passes = 1;
+        e->tot_scan_ms += ms; e->tot_pairs += e->pending_pairs; e->tot_launches += 1;
+    }
+    e->pending_timing = false;
+}
+
+extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end, uint32_t* rec_dev,
+                                      void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pairwise_argmin_dev: engine is NULL");
+    if (!rec_dev) return hm_fail(e, HM_E_ARG, "hm_pairwise_argmin_dev: NULL record pointer");
+    if (!(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pairwise_argmin_dev: curvature must be > 0");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    hm_flush_pending_timing(e);
+    const Bounds b = hm_bounds(thr, c);
+    ScanArgs a; dim3 grid;
+    if (b.none || e->n < 2 || !hm_prepare_scan(e, b, row_begin, row_end, a, grid)) {
+        HM_HIP(hipMemsetAsync(rec_dev, 0, sizeof(ArgminRec), s));        // found = 0
+        return HM_OK;
+    }
+    HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
+    HM_HIP(hipMemsetAsync(e->d_ctr64, 0xff, sizeof(unsigned long long) * 2, s));
+    HM_HIP(hipEventRecord(e->ev0, s));
+    HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s));
+    HM_HIP(hipEventRecord(e->ev1, s));
+    hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(HM_ARGMIN_BLOCKS), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img, e->RS,
+                       e->d, e->sign_mode, sqrtf(c), thr, e->d_parts);
+    HM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts,
+                       reinterpret_cast<ArgminRec*>(rec_dev), e->d_ctr, e->ent_cap);
+    HM_HIP(hipGetLastError());
+    e->pending_timing = true;
+    e->pending_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
+    return HM_OK;
+}
+
 extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end, float* d, int32_t* i,
                                   int32_t* j, int32_t* found, void* stream)
 {
@@ -1250,6 +1296,7 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
     hipStream_t s = (hipStream_t)stream;
     HM_HIP(hipSetDevice(e->device));
     *found = 0; *d = 0.f; *i = -1; *j = -1;
+    hm_flush_pending_timing(e);
     e->last_scan_ms = 0.f; e->last_pairs = 0; e->last_emitted = 0; e->last_passes = 0;
     const Bounds b = hm_bounds(thr, c);
     ScanArgs a; dim3 grid;
@@ -1266,7 +1313,7 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
         hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(HM_ARGMIN_BLOCKS), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img,
                            e->RS, e->d, e->sign_mode, sqrt_c, thr, e->d_parts);
         HM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec);
+        hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec, e->d_ctr, e->ent_cap);
         HM_HIP(hipGetLastError());
         HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
         HM_HIP(hipMemcpyAsync(e->h->ctr, e->d_ctr, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, s));
@@ -1283,7 +1330,7 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
         // overflow: the running key is the exact minimum over all published waves; rerun bounded by it
         if (pass == 1) return hm_fail(e, HM_E_CAPACITY, "hm_pairwise_argmin: emission buffer overflow on the bounded pass");
     }
-    if (e->h->rec.found) {
+    if (e->h->rec.found == 1u) {
         union { uint32_t u; float f; } cv; cv.u = e->h->rec.dbits;
         *found = 1; *d = cv.f; *i = (int32_t)e->h->rec.i; *j = (int32_t)e->h->rec.j;
     }
@@ -1402,6 +1449,7 @@ static int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row
     *n_valid_emitted = 0;
     *count = 0;
     *result_dev = nullptr;
+    hm_flush_pending_timing(e);
     e->last_scan_ms = 0.f; e->last_pairs = 0; e->last_emitted = 0; e->last_passes = 0;
     const Bounds b = hm_bounds(thr, c);
     ScanArgs a; dim3 grid;
@@ -1699,6 +1747,7 @@ extern "C" int hm_last_scan_stats(const hm_engine* e, float* scan_ms, int64_t* p
 extern "C" int hm_scan_totals(hm_engine* e, double* scan_ms, int64_t* pairs, int64_t* launches, int reset)
 {
     if (!e) return HM_E_ARG;
+    hm_flush_pending_timing(e);
     if (scan_ms) *scan_ms = e->tot_scan_ms;
     if (pairs) *pairs = e->tot_pairs;
     if (launches) *launches = e->tot_launches;

@@ -108,6 +108,14 @@ class MergeEngine:
             return None
         return float(d.value), int(i.value), int(j.value)
 
+    def argmin_into(self, c: float, thr: float, row_begin: int, row_end: int, rec: torch.Tensor) -> None:
+        """Asynchronous nearest-pair search: writes int32[4] {found, bits(d), i, j} into the device
+        tensor `rec` on the current stream (found = 2: buffer overflow, use ``argmin``)."""
+        if rec.device != self.device or rec.dtype != torch.int32 or rec.numel() < 4 or not rec.is_contiguous():
+            raise ValueError("rec must be a contiguous int32[4] tensor on the engine's device")
+        self._chk(self._L.hm_pairwise_argmin_dev(self._h, float(c), float(thr), int(row_begin), int(row_end),
+                                                 _ptr(rec), self._stream()))
+
     def topk(self, c: float, thr: float, k: int, row_begin: int = 0, row_end: int = -1):
         """k smallest candidates (d, i, j) in order and the exact candidate count."""
         k = int(k)

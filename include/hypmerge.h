@@ -72,6 +72,13 @@ int64_t hm_rows(const hm_engine* e);                     /* live rows in the ima
 int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end,
                        float* d, int32_t* i, int32_t* j, int32_t* found, void* stream);
 
+/* K1, device-resident form for the multi-GPU exchange: same search, but the 16-byte record
+ * {found, bits(d), i, j} (uint32 x 4; found = 2 means "emission buffer overflowed, call the host
+ * form") is written to rec_dev and nothing is synchronised -- the record can feed an RCCL
+ * all-gather on the same stream directly. */
+int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end,
+                           uint32_t* rec_dev, void* stream);
+
 /* K2: the k smallest candidates in order, and the exact number of candidates.
  * d_out/i_out/j_out have room for k entries (may be NULL when k == 0); *n_out = min(k, *count).
  * Replaces: the recompute branch of _find_merge_candidates_fast + candidates.sort() +

@@ -152,3 +152,52 @@ def test_full_size_properties(V, d):
     assert torch.isnan(table[V + 1]).all()
     c2 = eng.argmin(1.0, thr)
     assert (c2[1], c2[2]) == (row, V)
+
+
+def test_device_record_and_world1_nccl_shard(oracle):
+    """asynchronous argmin record (multi-GPU exchange path) equals the host form; a 1-rank RCCL
+    process group drives the sharded tokenizer through the same code the N-GPU run uses"""
+    import socket
+    import torch.distributed as dist
+    from hyptokenizer_amd.engine import MergeEngine
+    from hyptokenizer_amd.sharding import ShardContext
+    from hyptokenizer_amd.tokenizer.fast_hyperbolic_merge import FastHyperbolicTokenizer
+    from hyptokenizer_amd.tokenizer.hyperbolic_merge import HyperbolicTokenizer
+    n, d = 5000, 30
+    X = lorentz_table(n, d, seed=3, scale=0.05)
+    table = torch.zeros((n + 64, d + 1), device="cuda")
+    table[:n] = X.cuda()
+    eng = MergeEngine(n + 64, d + 1, "lorentz")
+    eng.set_table(table, n)
+    rec = torch.empty(4, dtype=torch.int32, device="cuda")
+    for thr, r0, r1 in ((0.3, 0, -1), (0.3, 1000, 2500), (1e-9, 0, -1)):
+        host = eng.argmin(1.0, thr, r0, r1)
+        eng.argmin_into(1.0, thr, r0, r1, rec)
+        got = rec.cpu().numpy()
+        if host is None:
+            assert got[0] == 0
+        else:
+            assert got[0] == 1 and (int(got[2]), int(got[3])) == (host[1], host[2])
+            assert np.uint32(got[1]) == np.float32(host[0]).view(np.uint32)
+    assert eng.scan_totals()["launches"] >= 6
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        ctx = ShardContext(device=torch.device("cuda", 0))
+        runs = []
+        for shard in (None, ctx):
+            tok = HyperbolicTokenizer(cjk_vocab(n), torch.nn.Parameter(X), merge_threshold=0.3, max_vocab_size=n + 64,
+                                      sign_convention="lorentz", shard=shard)
+            tok.optimize_merges(steps=12, log_every=10 ** 9)
+            ftok = FastHyperbolicTokenizer(cjk_vocab(n), torch.nn.Parameter(X), merge_threshold=0.3, max_vocab_size=n + 256,
+                                           sign_convention="lorentz", shard=shard)
+            ftok.optimize_merges(steps=120, log_every=10 ** 9, adaptive_threshold=False)
+            runs.append((list(tok.merge_history), tok.embeddings.data[n:n + 12].cpu(), list(ftok.merge_history)))
+        assert runs[0][0] == runs[1][0] and runs[0][2] == runs[1][2]
+        assert torch.equal(runs[0][1].view(torch.int32), runs[1][1].view(torch.int32))      # bits: NaN rows included
+    finally:
+        dist.destroy_process_group()
