@@ -16,9 +16,11 @@ problem (strong scaling), the best records are all-gathered over RCCL and every 
 merge to its replica.
 
 One JSON line on rank 0; see README/DESIGN.md for the fields.  `roofline` is for the dominant
-kernel (hm_scan_kernel, fp32 MFMA): achieved = N(N-1)(d+1) flops per launch (triangle only; the
-reference's dense convention would be 2x) / the launch duration measured with HIP events on the
-launch stream inside the timed region.  `cpu_baseline` times the oracle's OpenMP restatement of
+kernel of the timed run (hm_scan_kernel; by default its bf16-MFMA prefilter form, survivors are
+re-evaluated in the canonical fp32 arithmetic): achieved = N(N-1)(d+1) flops per launch (triangle
+only; the reference's dense convention would be 2x) / the launch duration measured with HIP events
+on the launch stream inside the timed region.  `roofline_fp32_form` is the same search with the
+exact fp32-MFMA prefilter (HM_SCAN_PRECISION=f32), timed right after on the same table.  `cpu_baseline` times the oracle's OpenMP restatement of
 the same search on a bounded row sample on this host's cores (rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -39,6 +41,7 @@ import torch.distributed as dist  # noqa: E402
 
 V, D, SCALE, SEED, THR, CURV = 50000, 100, 0.05, 42, 0.5, 1.0
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparsity figure)
 
 
 def cpu_baseline(X: np.ndarray, device, budget_s: float = 12.0) -> dict:
@@ -81,12 +84,12 @@ def cpu_baseline(X: np.ndarray, device, budget_s: float = 12.0) -> dict:
     }
 
 
-def traffic_from_profiles():
+def traffic_from_profiles(form: str):
     """Fabric-side bytes per scan launch from the committed PMC pass (profiles/*_pmc_scan_kernel.json:
     FETCH_SIZE x 1024 x 2 on gfx950 + WRITE_SIZE x 1024, MI355X_MICROARCH.md HBM section).  PMC
     counters cannot be collected from inside the timed run; same kernel, same size."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_scan_kernel.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_scan_kernel_{form}.json")))
     if not files:
         return None, None
     try:
@@ -175,12 +178,40 @@ def main() -> None:
         fast = {"merges_per_s": (len(ftok.merge_history) - 101) / tf, "steps": fsteps - 101,
                 "note": "FastHyperbolicTokenizer.optimize_merges: cache of 10000, one exact top-k search per ~101 steps"}
 
+    fp32_form = None
+    if rank == 0 and world == 1 and os.environ.get("HM_SCAN_PRECISION", "auto") != "f32":
+        from hyptokenizer_amd.engine import MergeEngine
+        os.environ["HM_SCAN_PRECISION"] = "f32"
+        try:
+            e32 = MergeEngine(V + 8, D + 1, "lorentz", device)
+            t32 = torch.zeros((V + 8, D + 1), dtype=torch.float32, device=device)
+            t32[:V] = X.to(device)
+            e32.set_table(t32, V)
+            for _ in range(3):
+                e32.argmin(CURV, THR)
+            e32.scan_totals(reset=True)
+            for _ in range(20):
+                r32 = e32.argmin(CURV, THR)
+            tt = e32.scan_totals()
+            ms32 = tt["scan_ms"] / tt["launches"]
+            fl32 = 2.0 * (D + 1) * tt["pairs"] / tt["launches"]
+            fp32_form = {"bound": "mfma", "achieved": fl32 / (ms32 * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": fl32 / (ms32 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "kernel": "hm_scan_kernel<NG=25,lorentz,ARGMIN,fp32>", "avg_launch_ms": ms32, "launches": tt["launches"],
+                         "nearest_pair": list(r32) if r32 else None}
+        finally:
+            os.environ.pop("HM_SCAN_PRECISION", None)
+
     if rank == 0:
         launches = sum(p[2] for p in per_rank)
         avg_ms = sum(p[0] for p in per_rank) / max(launches, 1.0)           # mean launch duration
         flops_per_launch = 2.0 * (D + 1) * sum(p[1] for p in per_rank) / max(launches, 1.0)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic, traffic_src = traffic_from_profiles() if world == 1 else (None, None)
+        form = os.environ.get("HM_SCAN_PRECISION", "auto")
+        bf16 = form != "f32"                     # auto picks the bf16 prefilter at d = 100
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        kernel_name = "hm_scan_kernel<KS=7,lorentz,ARGMIN,bf16>" if bf16 else "hm_scan_kernel<NG=25,lorentz,ARGMIN,fp32>"
+        traffic, traffic_src = traffic_from_profiles("bf16" if bf16 else "f32") if world == 1 else (None, None)
         n_mid = V + args.warmup + args.steps / 2.0
         scan_ms_per_step = max(p[0] / max(p[2], 1.0) for p in per_rank)     # slowest rank's scan per step
         out = {
@@ -194,19 +225,21 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16 prefilter + f32 canonical" if os.environ.get("HM_SCAN_PRECISION", "auto") != "f32" else "f32",
             "data": "synthetic",
             "config": {"workload": f"HyperbolicTokenizer.optimize_merges, full all-pairs search every step, V={V} d={D} "
                                    f"fp32, lorentz sign, thr={THR}, c={CURV}, scale={SCALE}, seed={SEED}",
                        "vocab": V, "dim": D, "merge_threshold": THR, "parallelism": f"rows sharded over {world} rank(s)"},
             "pairwise_dist_GBps_effective": (n_mid * n_mid * 4.0) / (scan_ms_per_step * 1e-3) / 1e9,
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": ("bytes per launch past the XCD L2s (FETCH_SIZE corrected x2 + WRITE_SIZE) from "
-                                          f"profiles/{traffic_src}; they are served by the Infinity Cache (the scan image "
-                                          "is 21.6 MB), compulsory bytes = the image once") if traffic else None,
-                         "kernel": "hm_scan_kernel<25,1,ARGMIN>", "avg_launch_ms": avg_ms,
-                         "flops_per_launch": flops_per_launch, "launches": launches},
+                                          f"profiles/{traffic_src}; served by the Infinity Cache (the scan image is "
+                                          "resident), compulsory bytes = the image once") if traffic else None,
+                         "kernel": kernel_name, "avg_launch_ms": avg_ms,
+                         "flops_per_launch": flops_per_launch, "launches": launches,
+                         "note": "flops = N(N-1)(d+1) algorithmic (triangle); peak = dense MFMA peak of the prefilter's dtype"},
+            "roofline_fp32_form": fp32_form,
             "fast_path": fast,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -24,6 +24,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -35,6 +36,7 @@
 #pragma clang fp contract(off)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------------------------
 // constants
@@ -46,7 +48,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define HM_PREFETCH_B 1            // fetch B fragments one k-group ahead of their MFMAs
 #endif
 #ifndef HM_CHUNK_TILES
-#define HM_CHUNK_TILES 32          // column tiles per block (upper bound; shrunk for small tables)
+#define HM_CHUNK_TILES 32          // fp32 form: column tiles per block (upper bound; shrunk for small tables)
+#endif
+#ifndef HM_CHUNK_TILES_BF16
+#define HM_CHUNK_TILES_BF16 128    // bf16 form: tiles are ~5x shorter, so blocks take more of them
 #endif
 #ifndef HM_TAIL_FRACTION
 #define HM_TAIL_FRACTION 0.15      // share of the work issued last in quarter-size chunks
@@ -72,11 +77,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef HM_MIN_WAVES
 #define HM_MIN_WAVES 2             // __launch_bounds__ second argument (waves per SIMD): 2 blocks per CU
 #endif
-#ifndef HM_TM
-#define HM_TM 1                    // 32-row MFMA tiles per wave along the stationary rows (1 or 2)
+#ifndef HM_TM_F32
+#define HM_TM_F32 1                // fp32 form: 32-row MFMA tiles per wave (block = 128 rows, 2 blocks per CU)
 #endif
-#define HM_WAVE_ROWS (32 * HM_TM)
-#define HM_ROWS_PER_BLOCK (4 * HM_WAVE_ROWS)   // 4 waves
+#ifndef HM_TM_BF16
+#define HM_TM_BF16 1               // bf16 form: 32-row MFMA tiles per wave
+#endif
+#ifndef HM_DIST_BF16
+#define HM_DIST_BF16 1             // bf16 form: tiles in flight ahead of the computed one (ring of DIST + 1 slots; deeper rings measured no gain)
+#endif
+#ifndef HM_WPB_BF16
+#define HM_WPB_BF16 4              // bf16 form: waves per block (all share each streamed 64-row tile)
+#endif
+#define HM_MAX_BLOCK_ROWS 512
 #define HM_COLS_PER_TILE 64        // partner rows per LDS tile
 #define HM_TIE_SLACK 1024u         // ulps of u' that are treated as "may still order before" (d is 2.5-ulp monotone)
 #define HM_MODE_TOPK 0
@@ -95,6 +108,8 @@ __host__ __device__ __forceinline__ int hm_tri_cum(int R, int chunks, int m)
 
 struct ScanArgs {
     const float* img;
+    const unsigned char* img16;   // bf16 image (BF = 1 kernels)
+    int bf16;                     // host-side: which form this launch uses
     int n;                  // live rows
     int row_begin, row_end; // i range
     int rb_first;           // first row block
@@ -124,7 +139,7 @@ struct ScanArgs {
     uint32_t hist_lo;
     uint32_t hist_shift;
     int sample_stride;
-    const uint32_t* rmax2_bits; // largest squared row norm (float bits), see hm_rownorm_kernel
+    const uint32_t* rmax2_bits; // [0] largest squared row norm, [1] largest squared spatial norm (float bits)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -180,21 +195,59 @@ __device__ __forceinline__ float hm_img_u(const float* img, int RS, int d, int64
     return sign_mode ? m : -m;
 }
 
-// largest squared row norm of the live rows (finite rows only), kept as float bits for atomicMax.
-// It scales the bound |u_fast - u_canonical| <= (d + 8) * 2^-23 * rmax2 used by the pair scan.
+// largest squared row norm [0] and largest squared spatial norm [1] of the live rows (finite rows
+// only), kept as float bits for atomicMax.  They scale the bound |u_f - u_c| used by the pair scan.
 __global__ void hm_rownorm_kernel(const float* __restrict__ img, int RS, int64_t row_begin, int64_t row_end,
                                   uint32_t* __restrict__ rmax2_bits)
 {
     const int64_t row = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float r2 = 0.0f;
+    float r2 = 0.0f, s2 = 0.0f;
     if (row < row_end) {
         const float* rr = img + row * RS;
-        for (int k = 0; k < RS; ++k) r2 = __builtin_fmaf(rr[k], rr[k], r2);
+        for (int k = 0; k < RS - 4; ++k) s2 = __builtin_fmaf(rr[k], rr[k], s2);
+        r2 = __builtin_fmaf(rr[RS - 4], rr[RS - 4], s2);
     }
-    if (!(r2 < 3.0e38f)) r2 = 0.0f;                 // NaN / inf rows never form candidates
+    if (!(r2 < 3.0e38f)) { r2 = 0.0f; s2 = 0.0f; }      // NaN / inf rows never form candidates
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) r2 = __builtin_fmaxf(r2, __shfl_xor(r2, off, 64));
-    if ((threadIdx.x & 63) == 0 && r2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(r2));
+    for (int off = 32; off > 0; off >>= 1) {
+        r2 = __builtin_fmaxf(r2, __shfl_xor(r2, off, 64));
+        s2 = __builtin_fmaxf(s2, __shfl_xor(s2, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (r2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(r2));
+        if (s2 > 0.0f) atomicMax(rmax2_bits + 1, hm::fbits(s2));
+    }
+}
+
+// bf16 image row: KS x 16 spatial coordinates in natural order as bf16 (round to nearest even, zero
+// padded), then one 16-byte chunk [x0 as fp32, 0, 0, 0].  2*KS + 1 chunks per row: always odd, so the
+// ds_read_b128 fragment reads of 32 consecutive rows fall on distinct 16-byte bank slots.
+__device__ __forceinline__ uint32_t hm_pack_bf16(float lo, float hi)
+{
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+    return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+__global__ void hm_build_image16_kernel(const float* __restrict__ X, int64_t ld, int d, int KS, unsigned char* __restrict__ img16,
+                                        int64_t row_begin, int64_t row_end)
+{
+    const int CH = 2 * KS + 1;                        // 16-byte chunks per row
+    const int64_t total = (row_end - row_begin) * CH;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = row_begin + t / CH;
+        const int c = (int)(t % CH);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const float* xr = X + row * ld;
+        if (c == CH - 1) {
+            v.x = hm::fbits(xr[0]);
+        } else {
+            float f[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int sidx = 8 * c + q; f[q] = sidx < d ? xr[1 + sidx] : 0.0f; }
+            v = make_uint4(hm_pack_bf16(f[0], f[1]), hm_pack_bf16(f[2], f[3]), hm_pack_bf16(f[4], f[5]), hm_pack_bf16(f[6], f[7]));
+        }
+        *reinterpret_cast<uint4*>(img16 + (row * CH + c) * 16) = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -220,15 +273,29 @@ __device__ __forceinline__ uint32_t hm_wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
-template <int NG, int SIGN, int MODE>
-__global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanArgs p)
+// BF = 0: exact fp32 prefilter (v_mfma_f32_32x32x2_f32 on the fp32 image; NG = groups of 4 spatial
+//         coordinates).  BF = 1: bf16 prefilter (v_mfma_f32_32x32x16_bf16 on the bf16 image, spatial
+//         part only; NG = k-steps of 16; the time product x0*y0 is added in fp32 in the epilogue).
+// Either way the result only selects survivors; every reported distance is re-evaluated with the
+// canonical arithmetic, and the bound `delta` on |u_f - u_c| widens every comparison accordingly.
+// TM = 32-row MFMA tiles per wave along the stationary rows (block = 4 waves = 128*TM rows).
+template <int NG, int SIGN, int MODE, int BF, int TM, int WPB>
+__global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const ScanArgs p)
 {
-    constexpr int RS = hm_row_floats(NG);          // floats per image row
-    constexpr int TILE_FLOATS = HM_COLS_PER_TILE * RS;
-    constexpr int NP = NG + 1;                     // k-groups: NG spatial + time
-    constexpr int NPIECE = RS / 4;                 // 1 KiB pieces per 64-row tile (one per 16-byte chunk column)
-    constexpr int TCH = RS / 4 - 1;                // chunk index of the time group
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 * TILE_FLOATS (+ hist)
+    constexpr int RS = hm_row_floats(NG);          // fp32 image: floats per row
+    constexpr int RB16 = 32 * NG + 16;             // bf16 image: bytes per row (NG x 16 bf16 + [x0 fp32, pad])
+    constexpr int TILE_BYTES = BF ? HM_COLS_PER_TILE * RB16 : HM_COLS_PER_TILE * RS * 4;
+    constexpr int NP = BF ? NG : NG + 1;           // k-steps: fp32: NG spatial groups + time; bf16: NG steps of 16
+    constexpr int NPIECE = TILE_BYTES / 1024;      // 1 KiB pieces per 64-row tile (one per 16-byte chunk column)
+    constexpr int TCH = RS / 4 - 1;                // fp32 image: chunk index of the time group
+    constexpr int PPW = (NPIECE + WPB - 1) / WPB;  // LDS-DMA pieces per wave and tile (tile padded to PPW * WPB KiB)
+    constexpr int TILE_LDS = PPW * WPB * 1024;     // LDS bytes per ring slot
+    constexpr int DIST = BF ? HM_DIST_BF16 : 1;    // tiles in flight ahead of the one being computed
+    constexpr int NBUF = DIST + 1;                 // ring slots
+    constexpr int WAVE_ROWS = 32 * TM;
+    constexpr int BLOCK_ROWS = WPB * WAVE_ROWS;     // WPB waves per block share every streamed tile
+    constexpr int NTHREADS = 64 * WPB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF * TILE_LDS (+ hist)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -266,18 +333,21 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
         ct0 = p.ctmin_b + slot_to_chunk(it % p.chunks_b) * p.ch_b;
         ct1 = ct0 + p.ch_b;
     }
-    if (ct0 < (rb * HM_ROWS_PER_BLOCK) / HM_COLS_PER_TILE) ct0 = (rb * HM_ROWS_PER_BLOCK) / HM_COLS_PER_TILE;   // left of the diagonal: no i < j
+    if (ct0 < (rb * BLOCK_ROWS) / HM_COLS_PER_TILE) ct0 = (rb * BLOCK_ROWS) / HM_COLS_PER_TILE;   // left of the diagonal: no i < j
     if (ct1 > p.nct) ct1 = p.nct;
     if (ct0 >= ct1) return;
 
-    const int i0w = rb * HM_ROWS_PER_BLOCK + wave * HM_WAVE_ROWS;   // first stationary row of this wave
-    const bool wave_active = (i0w < p.row_end) && (i0w + HM_WAVE_ROWS - 1 >= p.row_begin) && (i0w < p.n);
-    const bool rows_full = (i0w >= p.row_begin) && (i0w + HM_WAVE_ROWS - 1 < p.row_end);
+    const int i0w = rb * BLOCK_ROWS + wave * WAVE_ROWS;   // first stationary row of this wave
+    const bool wave_active = (i0w < p.row_end) && (i0w + WAVE_ROWS - 1 >= p.row_begin) && (i0w < p.n);
+    const bool rows_full = (i0w >= p.row_begin) && (i0w + WAVE_ROWS - 1 < p.row_end);
 
     // The MFMA result u_f (plain fmaf chain) and the canonical u_c (torch reduction order) are two
     // roundings of the same exact form; |u_f - u_c| <= delta (gamma_n bound on both, |terms| <= rmax2).
-    const float rmax2 = hm::bitsf(*p.rmax2_bits);
-    const float delta = ((float)(RS + 4) * 1.1920929e-07f) * rmax2 * 1.0001f;
+    const float rmax2 = hm::bitsf(p.rmax2_bits[0]);
+    float delta = ((float)((BF ? 16 * NG : RS) + 8) * 1.1920929e-07f) * rmax2 * 1.0001f;
+    // bf16 operands: each spatial product carries <= 2 * 2^-9 (+ 2^-18) relative error, so the sum is
+    // off by <= 2^-8 (1 + 2^-9) * ||x_s|| ||y_s|| <= 0.00392 * (largest squared spatial norm)
+    if (BF) delta += 0.00392f * hm::bitsf(p.rmax2_bits[1]);
     const float pre_f = p.u_hi + delta;              // candidate prefilter on u_f
     const float lo_f = p.u_lo - delta;               // u_f below this: canonical d < thr for sure
     const float zmax_f = 1.0f - delta;               // u_f at or below this: canonical u <= 1, d == 0
@@ -286,18 +356,34 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
 
     uint32_t* lhist = nullptr;
     if (MODE == HM_MODE_HIST) {
-        lhist = reinterpret_cast<uint32_t*>(smem + 2 * TILE_FLOATS);
-        for (int t = threadIdx.x; t < HM_HIST_BINS; t += 256) lhist[t] = 0;
+        lhist = reinterpret_cast<uint32_t*>(smem + NBUF * TILE_LDS);
+        for (int t = threadIdx.x; t < HM_HIST_BINS; t += NTHREADS) lhist[t] = 0;
     }
 
     // ---- stationary A fragments: lane (r, h) keeps its operands of every k-step in registers ----
-    float2 a[HM_TM][NP];
+    float2 a[BF ? 1 : TM][BF ? 1 : NP];            // fp32 form: 2 operands (two k-steps) per group
+    uint4 a16[BF ? TM : 1][BF ? NP : 1];           // bf16 form: 8 bf16 per 16-wide k-step
+    float nx0[BF ? TM : 1][16];                    // bf16 form: -x0 of the 16 rows this lane's accumulators hold
+    if constexpr (BF) {
 #pragma unroll
-    for (int tm = 0; tm < HM_TM; ++tm) {
-        const float* src = p.img + (int64_t)(i0w + 32 * tm + r) * RS + 2 * h;
+        for (int tm = 0; tm < TM; ++tm) {
+            const unsigned char* src = p.img16 + (int64_t)(i0w + 32 * tm + r) * RB16 + 16 * h;
 #pragma unroll
-        for (int g = 0; g < NP; ++g) a[tm][g] = *reinterpret_cast<const float2*>(src + 4 * (g < NG ? g : TCH));
-        a[tm][NG].x = -a[tm][NG].x;                // time step: acc = S - x0*y0 = -M
+            for (int g = 0; g < NP; ++g) a16[tm][g] = *reinterpret_cast<const uint4*>(src + 32 * g);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i0w + 32 * tm + (e & 3) + 8 * (e >> 2) + 4 * h;
+                nx0[tm][e] = -*reinterpret_cast<const float*>(p.img16 + (int64_t)row * RB16 + 32 * NG);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const float* src = p.img + (int64_t)(i0w + 32 * tm + r) * RS + 2 * h;
+#pragma unroll
+            for (int g = 0; g < NP; ++g) a[tm][g] = *reinterpret_cast<const float2*>(src + 4 * (g < NG ? g : TCH));
+            a[tm][NG].x = -a[tm][NG].x;            // time step: acc = S - x0*y0 = -M
+        }
     }
 
     // ---- LDS-DMA of one 64-row tile: NP pieces of 1 KiB, piece q handled by wave q % 4.
@@ -305,21 +391,28 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
     // the tile being computed; the matching wait is the explicit vmcnt(0) in front of the barrier
     // that ends each iteration (cdna_hip_programming.md section 5.7, LDS-DMA recipe).
     const uint32_t lds_base = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)smem);
-    auto dma_piece = [&](int ct, int buf, int q) {          // q: wave-uniform piece index
-        if (q < NPIECE) {
-            const char* src = reinterpret_cast<const char*>(p.img + (int64_t)ct * TILE_FLOATS) + lane * 16 + q * 1024;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * (uint32_t)(TILE_FLOATS * 4) + (uint32_t)q * 1024u);
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(src), "s"(dst)
-                         : "memory");
-        }
+    auto dma_piece = [&](int ct, int buf, int q) {          // q: wave-uniform piece index in [0, PPW * WPB)
+        // pieces past NPIECE (ring-slot padding) read the first KiB of the next tile: in bounds, unused
+        const char* src = (BF ? reinterpret_cast<const char*>(p.img16) : reinterpret_cast<const char*>(p.img)) +
+                          (int64_t)ct * TILE_BYTES + lane * 16 + q * 1024;
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * (uint32_t)TILE_LDS + (uint32_t)q * 1024u);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(dst)
+                     : "memory");
     };
-    constexpr int PPW = (NPIECE + 3) / 4;                   // pieces per wave
     auto dma_tile = [&](int ct, int buf) {
 #pragma unroll
-        for (int t = 0; t < PPW; ++t) dma_piece(ct, buf, t * 4 + wave);
+        for (int t = 0; t < PPW; ++t) dma_piece(ct, buf, t * WPB + wave);
+    };
+    // every wave issues exactly PPW pieces per tile, so "tile x has landed" is a counted wait:
+    // all but the (tiles issued after x) * PPW youngest vector-memory operations are complete
+    auto wait_tiles_in_flight = [&](int tiles) {
+        if (tiles <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else if (tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW < 63 ? 3 * PPW : 63) : "memory");
     };
 
     // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
@@ -337,82 +430,126 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
     const int rot = (HM_TILE_ROTATE && p.swizzle) ? (int)((unsigned)(rb * 5) % (unsigned)ntile) : 0;
     auto tile_at = [&](int t) { int q = t + rot; if (q >= ntile) q -= ntile; return ct0 + q * ct_step; };
 
-    dma_tile(tile_at(0), 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ring prologue: tiles 0 .. DIST-1 in flight, tile 0 landed
+#pragma unroll
+    for (int q = 0; q < DIST; ++q)
+        if (q < ntile) dma_tile(tile_at(q), q);
+    wait_tiles_in_flight((ntile < DIST ? ntile : DIST) - 1);
     __syncthreads();
 
     uint32_t sure_total = 0;         // per-lane partial of the sure count
-    int buf = 0;
+    int buf = 0;                     // ring slot of tile t
+    unsigned long long gk = ~0ull;   // last value read of the running argmin key
 
-    for (int t = 0; t < ntile; ++t, buf ^= 1) {
+
+    for (int t = 0; t < ntile; ++t) {
         const int ct = tile_at(t);
-        const bool has_next = (t + 1 < ntile);               // block-uniform
-        const int ct_next = has_next ? tile_at(t + 1) : ct;
+        const bool has_next = (t + DIST < ntile);            // block-uniform: a tile to put in flight
+        const int ct_next = has_next ? tile_at(t + DIST) : ct;
+        int buf_next = buf + DIST;                           // slot of tile t + DIST = slot of tile t - 1:
+        if (buf_next >= NBUF) buf_next -= NBUF;              // every wave left it at the previous barrier
 
         const int j0 = ct * HM_COLS_PER_TILE;
         const bool compute = wave_active && (j0 + 63 > i0w);
 
-        if (!HM_DMA_INTERLEAVE || !compute || NP - 1 < PPW) {
-            if (has_next) dma_tile(ct_next, buf ^ 1);
+        if (!HM_DMA_INTERLEAVE || !compute || (BF ? NP < PPW : NP - 1 < PPW)) {
+            if (has_next) dma_tile(ct_next, buf_next);
         }
+        f32x16 acc[TM][2];
         if (compute) {
-            unsigned long long gk = ~0ull;
-            if (MODE == HM_MODE_ARGMIN)
+            // running best key of the argmin search, refreshed every 8th tile only: hipcc waits for
+            // this vector load with vmcnt(0), which also drains the LDS-DMA ring.  A stale key only
+            // emits a few more entries.
+            if (MODE == HM_MODE_ARGMIN && (t & 7) == 0)
                 gk = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            f32x16 acc[HM_TM][2];
 #pragma unroll
-            for (int tm = 0; tm < HM_TM; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.0f;
 
-            // B fragments (optionally fetched one k-group ahead of the MFMAs that consume them)
-            const float* bt = smem + buf * TILE_FLOATS + r * RS + 2 * h;
+            if constexpr (BF) {
+                // bf16 prefilter: S = sum over the spatial coordinates, 16 per MFMA, fp32 accumulate
+                const char* bt = smem + buf * TILE_LDS + r * RB16 + 16 * h;
+                uint4 b0 = *reinterpret_cast<const uint4*>(bt);
+                uint4 b1 = *reinterpret_cast<const uint4*>(bt + 32 * RB16);
+                const float y0a = *reinterpret_cast<const float*>(smem + buf * TILE_LDS + r * RB16 + 32 * NG);
+                const float y0b = *reinterpret_cast<const float*>(smem + buf * TILE_LDS + (32 + r) * RB16 + 32 * NG);
+#pragma unroll
+                for (int g = 0; g < NP; ++g) {
+                    uint4 n0 = b0, n1 = b1;
+                    if (g + 1 < NP) {
+                        n0 = *reinterpret_cast<const uint4*>(bt + 32 * (g + 1));
+                        n1 = *reinterpret_cast<const uint4*>(bt + 32 * RB16 + 32 * (g + 1));
+                    }
+                    if (HM_DMA_INTERLEAVE && g < PPW && has_next) dma_piece(ct_next, buf_next, g * WPB + wave);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
+                                                                            __builtin_bit_cast(bf16x8, b0), acc[tm][0], 0, 0, 0);
+                        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
+                                                                            __builtin_bit_cast(bf16x8, b1), acc[tm][1], 0, 0, 0);
+                    }
+                    b0 = n0;
+                    b1 = n1;
+                }
+                // time product in fp32: acc = S - x0*y0 (= -M), the convention of the fp32 form
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        acc[tm][0][e] = __builtin_fmaf(nx0[tm][e], y0a, acc[tm][0][e]);
+                        acc[tm][1][e] = __builtin_fmaf(nx0[tm][e], y0b, acc[tm][1][e]);
+                    }
+            } else {
+                // B fragments (optionally fetched one k-group ahead of the MFMAs that consume them)
+                const float* bt = reinterpret_cast<const float*>(smem + buf * TILE_LDS) + r * RS + 2 * h;
 #if HM_PREFETCH_B
-            float2 b0 = *reinterpret_cast<const float2*>(bt);
-            float2 b1 = *reinterpret_cast<const float2*>(bt + 32 * RS);
+                float2 b0 = *reinterpret_cast<const float2*>(bt);
+                float2 b1 = *reinterpret_cast<const float2*>(bt + 32 * RS);
 #endif
 #pragma unroll
-            for (int g = 0; g < NP; ++g) {
+                for (int g = 0; g < NP; ++g) {
 #if HM_PREFETCH_B
-                float2 n0 = b0, n1 = b1;
-                if (g + 1 < NP) {
-                    n0 = *reinterpret_cast<const float2*>(bt + 4 * (g + 1 < NG ? g + 1 : TCH));
-                    n1 = *reinterpret_cast<const float2*>(bt + 32 * RS + 4 * (g + 1 < NG ? g + 1 : TCH));
-                }
+                    float2 n0 = b0, n1 = b1;
+                    if (g + 1 < NP) {
+                        n0 = *reinterpret_cast<const float2*>(bt + 4 * (g + 1 < NG ? g + 1 : TCH));
+                        n1 = *reinterpret_cast<const float2*>(bt + 32 * RS + 4 * (g + 1 < NG ? g + 1 : TCH));
+                    }
 #else
-                const float2 b0 = *reinterpret_cast<const float2*>(bt + 4 * (g < NG ? g : TCH));
-                const float2 b1 = *reinterpret_cast<const float2*>(bt + 32 * RS + 4 * (g < NG ? g : TCH));
+                    const float2 b0 = *reinterpret_cast<const float2*>(bt + 4 * (g < NG ? g : TCH));
+                    const float2 b1 = *reinterpret_cast<const float2*>(bt + 32 * RS + 4 * (g < NG ? g : TCH));
 #endif
 #if HM_DMA_INTERLEAVE
-                // next tile's LDS-DMA pieces are issued between the MFMAs of the first k-groups: their
-                // issue slots hide behind the 64-cycle matrix instructions
-                if (NP - 1 >= PPW && g >= 1 && g - 1 < PPW && has_next) dma_piece(ct_next, buf ^ 1, (g - 1) * 4 + wave);
+                    // next tile's LDS-DMA pieces are issued between the MFMAs of the first k-groups: their
+                    // issue slots hide behind the 64-cycle matrix instructions
+                    if (NP - 1 >= PPW && g >= 1 && g - 1 < PPW && has_next) dma_piece(ct_next, buf_next, (g - 1) * WPB + wave);
 #endif
 #pragma unroll
-                for (int tm = 0; tm < HM_TM; ++tm) {
-                    acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].x, b0.x, acc[tm][0], 0, 0, 0);
-                    acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].x, b1.x, acc[tm][1], 0, 0, 0);
-                }
-                if (g < NG) {
-#pragma unroll
-                    for (int tm = 0; tm < HM_TM; ++tm) {
-                        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].y, b0.y, acc[tm][0], 0, 0, 0);
-                        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].y, b1.y, acc[tm][1], 0, 0, 0);
+                    for (int tm = 0; tm < TM; ++tm) {
+                        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].x, b0.x, acc[tm][0], 0, 0, 0);
+                        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].x, b1.x, acc[tm][1], 0, 0, 0);
                     }
-                }
+                    if (g < NG) {
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) {
+                            acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].y, b0.y, acc[tm][0], 0, 0, 0);
+                            acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].y, b1.y, acc[tm][1], 0, 0, 0);
+                        }
+                    }
 #if HM_PREFETCH_B
-                b0 = n0;
-                b1 = n1;
+                    b0 = n0;
+                    b1 = n1;
 #endif
+                }
             }
             // acc = S - x0*y0 = -M.  u = -M (reference sign) = acc;  u = +M (lorentz) = -acc.
 
             // ---- fast check: the lane's most promising u against the current bound ----
             float ext = acc[0][0][0];
 #pragma unroll
-            for (int tm = 0; tm < HM_TM; ++tm)
+            for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -423,7 +560,7 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
             float bound_f = pre_f;
             uint32_t best_bits = 0xffffffffu, best_low = 0xffffffffu;
             if (MODE == HM_MODE_ARGMIN) {
-                // running best key over everything published so far (loaded before the MFMA loop so
+                // running best key over everything published so far (requested before the MFMA loop so
                 // that its latency is hidden); an entry can only order before it if its u_f is within
                 // 2*delta (+ a few ulps of acosh wiggle) of the best u_f
                 best_bits = (uint32_t)(gk >> 32);
@@ -435,7 +572,7 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
             }
 
             if (__ballot(ext_u < bound_f) != 0ull) {
-                const bool full = rows_full && (j0 > i0w + HM_WAVE_ROWS - 1) && (j0 + 63 < p.n);
+                const bool full = rows_full && (j0 > i0w + WAVE_ROWS - 1) && (j0 + 63 < p.n);
                 // -------- slow path: per-element predicates, evaluated twice (count, then write).
                 // The second evaluation runs on laundered copies of the bounds so that the compiler
                 // does not keep 64 predicates alive across the wave scan (that spills).
@@ -485,7 +622,7 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
                     ++slot;
                 };
 #pragma unroll
-                for (int tm = 0; tm < HM_TM; ++tm)
+                for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -502,7 +639,7 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
                         slot = base + incl - n_emit;
                         asm volatile("" : "+v"(bnd), "+v"(cutv));      // opaque: no CSE with the count pass
 #pragma unroll
-                        for (int tm = 0; tm < HM_TM; ++tm)
+                        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -515,8 +652,12 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile has landed (this wave's pieces)
-        __syncthreads();                                    // ... and every wave's; all reads of buf done
+        {   // tile t+1 has landed (this wave's pieces): tiles t+2 .. min(t+DIST, ntile-1) may stay in flight
+            const int last = (t + DIST < ntile - 1) ? t + DIST : ntile - 1;
+            wait_tiles_in_flight(last - (t + 1));
+        }
+        __syncthreads();                                    // ... and every wave's; all reads of slot `buf` done
+        if (++buf == NBUF) buf = 0;
     }
 
     if (MODE == HM_MODE_TOPK) {
@@ -528,7 +669,7 @@ __global__ __launch_bounds__(256, HM_MIN_WAVES) void hm_scan_kernel(const ScanAr
     }
     if (MODE == HM_MODE_HIST) {
         __syncthreads();
-        for (int t = threadIdx.x; t < HM_HIST_BINS; t += 256)
+        for (int t = threadIdx.x; t < HM_HIST_BINS; t += NTHREADS)
             if (lhist[t]) atomicAdd(&p.hist[t], lhist[t]);
     }
 }
@@ -781,7 +922,8 @@ __global__ void hm_midpoint_kernel(const float* __restrict__ img, int RS, int d,
 // sequential) canonical arithmetic on LDS operands, all lanes write the result.
 __global__ __launch_bounds__(64) void hm_merge_append_kernel(float* __restrict__ img, int RS, int d, int NG, int32_t i, int32_t j,
                                                              float w, float c, int sign_mode, float* __restrict__ X, int64_t ld,
-                                                             int64_t new_row, uint32_t* __restrict__ rmax2_bits)
+                                                             int64_t new_row, uint32_t* __restrict__ rmax2_bits,
+                                                             unsigned char* __restrict__ img16, int KS)
 {
     __shared__ float sx[HM_MAX_D1], sy[HM_MAX_D1], sv[HM_MAX_D1], so[HM_MAX_D1];
     const int lane = threadIdx.x;
@@ -795,7 +937,11 @@ __global__ __launch_bounds__(64) void hm_merge_append_kernel(float* __restrict__
         float r2 = 0.0f;
         hm_midpoint_core(d, w, c, sign_mode, [&](int k) { return sx[k]; }, [&](int k) { return sy[k]; },
                          [&](int k, float v) { so[k] = v; r2 = __builtin_fmaf(v, v, r2); }, sv);
-        if (r2 < 3.0e38f && r2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(r2));
+        if (r2 < 3.0e38f && r2 > 0.0f) {
+            atomicMax(rmax2_bits, hm::fbits(r2));
+            const float s2 = r2 - so[0] * so[0];
+            if (s2 > 0.0f) atomicMax(rmax2_bits + 1, hm::fbits(s2 * 1.0001f));
+        }
     }
     __syncthreads();
     float* xr = X + new_row * ld;
@@ -805,6 +951,20 @@ __global__ __launch_bounds__(64) void hm_merge_append_kernel(float* __restrict__
         xr[k] = v;
         if (k == 0) ir[RS - 4] = v;
         else ir[4 * ((k - 1) >> 2) + hm_pos_in_group((k - 1) & 3)] = v;
+    }
+    // bf16 image row
+    const int CH = 2 * KS + 1;
+    for (int cidx = lane; cidx < CH; cidx += 64) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (cidx == CH - 1) {
+            v.x = hm::fbits(so[0]);
+        } else {
+            float f[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int sidx = 8 * cidx + q; f[q] = sidx < d ? so[1 + sidx] : 0.0f; }
+            v = make_uint4(hm_pack_bf16(f[0], f[1]), hm_pack_bf16(f[2], f[3]), hm_pack_bf16(f[4], f[5]), hm_pack_bf16(f[6], f[7]));
+        }
+        *reinterpret_cast<uint4*>(img16 + ((int64_t)new_row * CH + cidx) * 16) = v;
     }
 }
 
@@ -905,12 +1065,16 @@ struct hm_engine {
     int64_t max_rows = 0, rows_alloc = 0, n = 0;
     int d1 = 0, d = 0, NG = 0, RS = 0, sign_mode = 0;
     float* img = nullptr;
+    unsigned char* img16 = nullptr;       // bf16 image for the bf16 prefilter form
+    int KS = 0, RB16 = 0;                 // k-steps of 16 and bytes per bf16 image row
+    int precision = 0;                    // 0 = auto, 1 = fp32 prefilter, 2 = bf16 prefilter
+    bool bf16_ok = true;                  // auto mode: reserved for a norm-based veto of the bf16 form
     uint4* ent = nullptr;
     uint4* ent2 = nullptr;
     uint4* sorted = nullptr;
     uint32_t ent_cap = 0;
     uint32_t* d_ctr = nullptr;            // 8 x u32
-    uint32_t* d_rmax2 = nullptr;          // float bits of the largest squared row norm
+    uint32_t* d_rmax2 = nullptr;          // float bits: [0] largest squared row norm, [1] largest squared spatial norm
     unsigned long long* d_ctr64 = nullptr; // 2 x u64
     ArgminRec* d_rec = nullptr;
     ArgminPart* d_parts = nullptr;
@@ -951,6 +1115,15 @@ static int hm_fail(hm_engine* e, int code, const std::string& msg)
 
 static const int kSupportedNG[] = {1, 2, 3, 4, 6, 8, 10, 13, 16, 20, 25, 28, 32};
 
+static const int kSupportedKS[] = {1, 2, 4, 7, 8};      // bf16 form: 16 spatial coordinates per k-step
+static int hm_pick_ks(int d)
+{
+    const int need = (d + 15) / 16;
+    for (int v : kSupportedKS)
+        if (v >= need) return v;
+    return -1;
+}
+
 static int hm_pick_ng(int d)
 {
     const int need = (d + 3) / 4;
@@ -990,18 +1163,26 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     e->NG = hm_pick_ng(e->d);
     e->RS = hm_row_floats(e->NG);
     e->sign_mode = sign_mode;
-    e->rows_alloc = (max_rows + HM_ROWS_PER_BLOCK - 1) / HM_ROWS_PER_BLOCK * HM_ROWS_PER_BLOCK + HM_ROWS_PER_BLOCK;
+    e->rows_alloc = (max_rows + HM_MAX_BLOCK_ROWS - 1) / HM_MAX_BLOCK_ROWS * HM_MAX_BLOCK_ROWS + HM_MAX_BLOCK_ROWS;
+    e->KS = hm_pick_ks(e->d);
+    e->RB16 = 32 * e->KS + 16;
+    {
+        const char* pe = getenv("HM_SCAN_PRECISION");          // "f32" | "bf16" | unset = auto
+        e->precision = (pe && !strcmp(pe, "f32")) ? 1 : (pe && !strcmp(pe, "bf16")) ? 2 : 0;
+    }
     e->ent_cap = 1u << 24;
     e->sorted_cap = 1u << 16;
     HM_HIP(hipSetDevice(device));
     HM_HIP(hipMalloc(&e->img, sizeof(float) * (size_t)e->rows_alloc * e->RS));
     HM_HIP(hipMemset(e->img, 0, sizeof(float) * (size_t)e->rows_alloc * e->RS));
+    HM_HIP(hipMalloc(&e->img16, (size_t)e->rows_alloc * e->RB16));
+    HM_HIP(hipMemset(e->img16, 0, (size_t)e->rows_alloc * e->RB16));
     HM_HIP(hipMalloc(&e->ent, sizeof(uint4) * (size_t)e->ent_cap));
     HM_HIP(hipMalloc(&e->ent2, sizeof(uint4) * (size_t)e->ent_cap));
     HM_HIP(hipMalloc(&e->sorted, sizeof(uint4) * (size_t)e->sorted_cap));
     HM_HIP(hipMalloc(&e->d_ctr, sizeof(uint32_t) * 8));
-    HM_HIP(hipMalloc(&e->d_rmax2, sizeof(uint32_t)));
-    HM_HIP(hipMemset(e->d_rmax2, 0, sizeof(uint32_t)));
+    HM_HIP(hipMalloc(&e->d_rmax2, sizeof(uint32_t) * 2));
+    HM_HIP(hipMemset(e->d_rmax2, 0, sizeof(uint32_t) * 2));
     HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 2));
     HM_HIP(hipMalloc(&e->d_rec, sizeof(ArgminRec)));
     HM_HIP(hipMalloc(&e->d_parts, sizeof(ArgminPart) * HM_ARGMIN_BLOCKS));
@@ -1018,7 +1199,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
 {
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
-    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts};
+    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts, e->img16};
     for (void* q : dev_ptrs) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);
     if (e->h_sorted) (void)hipHostFree(e->h_sorted);
@@ -1039,6 +1220,10 @@ static int hm_build_rows(hm_engine* e, const float* X, int64_t ld, int64_t r0, i
     HM_HIP(hipGetLastError());
     hipLaunchKernelGGL(hm_rownorm_kernel, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, s, e->img, e->RS, r0, r1, e->d_rmax2);
     HM_HIP(hipGetLastError());
+    const int64_t total16 = (r1 - r0) * (2 * e->KS + 1);
+    hipLaunchKernelGGL(hm_build_image16_kernel, dim3((unsigned)std::min<int64_t>((total16 + 255) / 256, 4096)), dim3(256), 0, s, X, ld,
+                       e->d, e->KS, e->img16, r0, r1);
+    HM_HIP(hipGetLastError());
     return HM_OK;
 }
 
@@ -1049,9 +1234,11 @@ extern "C" int hm_set_table(hm_engine* e, const float* X_dev, int64_t ld, int64_
         return hm_fail(e, HM_E_ARG, "hm_set_table: bad table pointer / ld / n_rows");
     hipStream_t s = (hipStream_t)stream;
     HM_HIP(hipSetDevice(e->device));
-    if (e->n > n_rows)   // rows that are no longer live must read as zeros (never candidates: masked)
+    if (e->n > n_rows) { // rows that are no longer live must read as zeros (never candidates: masked)
         HM_HIP(hipMemsetAsync(e->img + n_rows * e->RS, 0, sizeof(float) * (size_t)(e->n - n_rows) * e->RS, s));
-    HM_HIP(hipMemsetAsync(e->d_rmax2, 0, sizeof(uint32_t), s));
+        HM_HIP(hipMemsetAsync(e->img16 + n_rows * e->RB16, 0, (size_t)(e->n - n_rows) * e->RB16, s));
+    }
+    HM_HIP(hipMemsetAsync(e->d_rmax2, 0, sizeof(uint32_t) * 2, s));
     int rc = hm_build_rows(e, X_dev, ld, 0, n_rows, s);
     if (rc) return rc;
     e->n = n_rows;
@@ -1105,51 +1292,73 @@ static Bounds hm_bounds(float thr, float c)
     return b;
 }
 
-template <int NG, int SIGN, int MODE>
+template <int NG, int SIGN, int MODE, int BF, int TM, int WPB>
 static hipError_t hm_launch_scan_t(const ScanArgs& a, dim3 grid, hipStream_t s)
 {
-    size_t lds = sizeof(float) * 2 * HM_COLS_PER_TILE * hm_row_floats(NG);
+    const size_t tile_bytes = BF ? (size_t)HM_COLS_PER_TILE * (32 * NG + 16) : sizeof(float) * HM_COLS_PER_TILE * hm_row_floats(NG);
+    const size_t ppw = (tile_bytes / 1024 + WPB - 1) / WPB;
+    size_t lds = ((BF ? HM_DIST_BF16 : 1) + 1) * ppw * WPB * 1024;
     if (MODE == HM_MODE_HIST) lds += sizeof(uint32_t) * HM_HIST_BINS;
     static bool attr_set = false;    // per instantiation
     if (!attr_set && lds > 48 * 1024) {
-        hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(&hm_scan_kernel<NG, SIGN, MODE>),
+        hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(&hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (st != hipSuccess) return st;
         attr_set = true;
     }
-    hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB>), grid, dim3(64 * WPB), lds, s, a);
     return hipGetLastError();
 }
 
-template <int NG>
+template <int NG, int BF, int TM, int WPB>
 static hipError_t hm_launch_scan_ng(int sign, int mode, const ScanArgs& a, dim3 grid, hipStream_t s)
 {
     if (sign) {
-        if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 1, HM_MODE_TOPK>(a, grid, s);
-        if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 1, HM_MODE_ARGMIN>(a, grid, s);
-        return hm_launch_scan_t<NG, 1, HM_MODE_HIST>(a, grid, s);
+        if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 1, HM_MODE_TOPK, BF, TM, WPB>(a, grid, s);
+        if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 1, HM_MODE_ARGMIN, BF, TM, WPB>(a, grid, s);
+        return hm_launch_scan_t<NG, 1, HM_MODE_HIST, BF, TM, WPB>(a, grid, s);
     }
-    if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 0, HM_MODE_TOPK>(a, grid, s);
-    if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 0, HM_MODE_ARGMIN>(a, grid, s);
-    return hm_launch_scan_t<NG, 0, HM_MODE_HIST>(a, grid, s);
+    if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 0, HM_MODE_TOPK, BF, TM, WPB>(a, grid, s);
+    if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 0, HM_MODE_ARGMIN, BF, TM, WPB>(a, grid, s);
+    return hm_launch_scan_t<NG, 0, HM_MODE_HIST, BF, TM, WPB>(a, grid, s);
+}
+
+// Which prefilter form a scan uses.  The bf16 form's error bound 0.00392 * max||x_s||^2 only costs
+// extra emissions, never correctness; auto picks it from d >= 24 (below that the fp32 form is
+// already short) unless a norm-based veto is set.
+static bool hm_use_bf16(const hm_engine* e)
+{
+    if (e->precision == 1) return false;
+    if (e->precision == 2) return true;
+    return e->d >= 24 && e->bf16_ok;
 }
 
 static hipError_t hm_launch_scan(const hm_engine* e, int mode, const ScanArgs& a, dim3 grid, hipStream_t s)
 {
+    if (a.bf16) {
+        switch (e->KS) {
+            case 1: return hm_launch_scan_ng<1, 1, HM_TM_BF16, HM_WPB_BF16>(e->sign_mode, mode, a, grid, s);
+            case 2: return hm_launch_scan_ng<2, 1, HM_TM_BF16, HM_WPB_BF16>(e->sign_mode, mode, a, grid, s);
+            case 4: return hm_launch_scan_ng<4, 1, HM_TM_BF16, HM_WPB_BF16>(e->sign_mode, mode, a, grid, s);
+            case 7: return hm_launch_scan_ng<7, 1, HM_TM_BF16, HM_WPB_BF16>(e->sign_mode, mode, a, grid, s);
+            case 8: return hm_launch_scan_ng<8, 1, HM_TM_BF16, HM_WPB_BF16>(e->sign_mode, mode, a, grid, s);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (e->NG) {
-        case 1: return hm_launch_scan_ng<1>(e->sign_mode, mode, a, grid, s);
-        case 2: return hm_launch_scan_ng<2>(e->sign_mode, mode, a, grid, s);
-        case 3: return hm_launch_scan_ng<3>(e->sign_mode, mode, a, grid, s);
-        case 4: return hm_launch_scan_ng<4>(e->sign_mode, mode, a, grid, s);
-        case 6: return hm_launch_scan_ng<6>(e->sign_mode, mode, a, grid, s);
-        case 8: return hm_launch_scan_ng<8>(e->sign_mode, mode, a, grid, s);
-        case 10: return hm_launch_scan_ng<10>(e->sign_mode, mode, a, grid, s);
-        case 13: return hm_launch_scan_ng<13>(e->sign_mode, mode, a, grid, s);
-        case 16: return hm_launch_scan_ng<16>(e->sign_mode, mode, a, grid, s);
-        case 20: return hm_launch_scan_ng<20>(e->sign_mode, mode, a, grid, s);
-        case 25: return hm_launch_scan_ng<25>(e->sign_mode, mode, a, grid, s);
-        case 28: return hm_launch_scan_ng<28>(e->sign_mode, mode, a, grid, s);
-        case 32: return hm_launch_scan_ng<32>(e->sign_mode, mode, a, grid, s);
+        case 1: return hm_launch_scan_ng<1, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 2: return hm_launch_scan_ng<2, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 3: return hm_launch_scan_ng<3, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 4: return hm_launch_scan_ng<4, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 6: return hm_launch_scan_ng<6, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 8: return hm_launch_scan_ng<8, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 10: return hm_launch_scan_ng<10, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 13: return hm_launch_scan_ng<13, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 16: return hm_launch_scan_ng<16, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 20: return hm_launch_scan_ng<20, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 25: return hm_launch_scan_ng<25, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 28: return hm_launch_scan_ng<28, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 32: return hm_launch_scan_ng<32, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1163,10 +1372,13 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     if (row_begin >= row_end) return false;
     memset(&a, 0, sizeof(a));
     a.img = e->img;
+    a.img16 = e->img16;
+    a.bf16 = hm_use_bf16(e) ? 1 : 0;
+    const int block_rows = a.bf16 ? 32 * HM_TM_BF16 * HM_WPB_BF16 : 128 * HM_TM_F32;
     a.n = (int)e->n;
     a.row_begin = (int)row_begin;
     a.row_end = (int)row_end;
-    a.rb_first = (int)(row_begin / HM_ROWS_PER_BLOCK);
+    a.rb_first = (int)(row_begin / block_rows);
     a.nct = (int)((e->n + HM_COLS_PER_TILE - 1) / HM_COLS_PER_TILE);
     a.u_hi = b.u_hi;
     a.u_lo = b.u_lo;
@@ -1180,11 +1392,11 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     a.hist = e->d_hist;
     a.sample_stride = 1;
     a.rmax2_bits = e->d_rmax2;
-    const int rb_last = (int)((row_end - 1) / HM_ROWS_PER_BLOCK);
+    const int rb_last = (int)((row_end - 1) / block_rows);
     const int nrb = rb_last - a.rb_first + 1;
-    const int tiles_per_rb = HM_ROWS_PER_BLOCK / HM_COLS_PER_TILE;          // diagonal advance per row block
+    const int tiles_per_rb = block_rows / HM_COLS_PER_TILE;                  // diagonal advance per row block
     // column tiles per block: amortise the stationary-row load, but keep enough blocks in flight
-    int ch = HM_CHUNK_TILES;
+    int ch = a.bf16 ? HM_CHUNK_TILES_BF16 : HM_CHUNK_TILES;
     while (ch > 4 && (int64_t)nrb * ((a.nct + ch - 1) / ch) < 1024) ch >>= 1;
     // phase B = the last ~HM_TAIL_FRACTION of the work (row blocks near the bottom of the triangle),
     // cut into chunks a quarter the size
@@ -1648,7 +1860,7 @@ extern "C" int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, floa
         return hm_fail(e, HM_E_ARG, "hm_merge_append: bad arguments");
     HM_HIP(hipSetDevice(e->device));
     hipLaunchKernelGGL(hm_merge_append_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d, e->NG, i, j, w, c,
-                       e->sign_mode, X_dev, ld, new_row, e->d_rmax2);
+                       e->sign_mode, X_dev, ld, new_row, e->d_rmax2, e->img16, e->KS);
     HM_HIP(hipGetLastError());
     if (new_row < e->n) e->have_cut = false;
     if (new_row + 1 > e->n) e->n = new_row + 1;

@@ -16,6 +16,15 @@ from hyptokenizer_amd.synthetic import lorentz_table  # noqa: E402
 MODES = {"reference": 0, "lorentz": 1}
 
 
+@pytest.fixture(params=["f32", "bf16"], autouse=True)
+def prefilter_form(request, monkeypatch):
+    """Every test in this module runs twice: exact fp32 MFMA prefilter and bf16 MFMA prefilter
+    (HM_SCAN_PRECISION is read when an engine is created).  Results must be identical: the
+    prefilter only selects survivors, the canonical arithmetic decides."""
+    monkeypatch.setenv("HM_SCAN_PRECISION", request.param)
+    return request.param
+
+
 def _engine(X, mode, max_rows=None):
     from hyptokenizer_amd.engine import MergeEngine
     n, d1 = X.shape
