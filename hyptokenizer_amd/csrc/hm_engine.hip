@@ -219,13 +219,31 @@ __global__ void hm_rownorm_kernel(const float* __restrict__ img, int RS, int64_t
     }
 }
 
-// bf16 image row: KS x 16 spatial coordinates in natural order as bf16 (round to nearest even, zero
-// padded), then one 16-byte chunk [x0 as fp32, 0, 0, 0].  2*KS + 1 chunks per row: always odd, so the
-// ds_read_b128 fragment reads of 32 consecutive rows fall on distinct 16-byte bank slots.
+// bf16 image row: KS x 16 K-slots as bf16 (round to nearest even) followed by one 16-byte chunk
+// [x0 as fp32, 0, 0, 0] (2*KS + 1 chunks per row: always odd, so the ds_read_b128 fragment reads of
+// 32 consecutive rows fall on distinct 16-byte bank slots).  Slots 0..d-1 hold the spatial
+// coordinates; the LAST FOUR slots hold the time coordinate split as x0 ~ hi + lo:
+//   streamed (B) encoding  [hi, lo, hi, 0];  the stationary (A) side rewrites its copy in registers to
+//   [-hi, -hi, -lo, 0], so the MFMA adds -(hi*hi' + hi*lo' + lo*hi') = -x0*y0 (1 + O(2^-16)).
 __device__ __forceinline__ uint32_t hm_pack_bf16(float lo, float hi)
 {
     const __bf16 a = (__bf16)lo, b = (__bf16)hi;
     return (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+__device__ __forceinline__ uint4 hm_bf16_chunk(const float* spatial /* x[1..d] */, float x0, int d, int KS, int c)
+{
+    // chunk c covers K-slots 8c .. 8c+7
+    float f[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int sidx = 8 * c + q; f[q] = sidx < d ? spatial[sidx] : 0.0f; }
+    if (c == 2 * KS - 1) {
+        const __bf16 hb = (__bf16)x0;
+        const float hi = (float)hb;
+        const float lo = x0 - hi;
+        f[4] = hi; f[5] = lo; f[6] = hi; f[7] = 0.0f;
+    }
+    return make_uint4(hm_pack_bf16(f[0], f[1]), hm_pack_bf16(f[2], f[3]), hm_pack_bf16(f[4], f[5]), hm_pack_bf16(f[6], f[7]));
 }
 
 __global__ void hm_build_image16_kernel(const float* __restrict__ X, int64_t ld, int d, int KS, unsigned char* __restrict__ img16,
@@ -238,14 +256,8 @@ __global__ void hm_build_image16_kernel(const float* __restrict__ X, int64_t ld,
         const int c = (int)(t % CH);
         uint4 v = make_uint4(0, 0, 0, 0);
         const float* xr = X + row * ld;
-        if (c == CH - 1) {
-            v.x = hm::fbits(xr[0]);
-        } else {
-            float f[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { const int sidx = 8 * c + q; f[q] = sidx < d ? xr[1 + sidx] : 0.0f; }
-            v = make_uint4(hm_pack_bf16(f[0], f[1]), hm_pack_bf16(f[2], f[3]), hm_pack_bf16(f[4], f[5]), hm_pack_bf16(f[6], f[7]));
-        }
+        if (c == CH - 1) v.x = hm::fbits(xr[0]);
+        else v = hm_bf16_chunk(xr + 1, xr[0], d, KS, c);
         *reinterpret_cast<uint4*>(img16 + (row * CH + c) * 16) = v;
     }
 }
@@ -347,7 +359,8 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
     float delta = ((float)((BF ? 16 * NG : RS) + 8) * 1.1920929e-07f) * rmax2 * 1.0001f;
     // bf16 operands: each spatial product carries <= 2 * 2^-9 (+ 2^-18) relative error, so the sum is
     // off by <= 2^-8 (1 + 2^-9) * ||x_s|| ||y_s|| <= 0.00392 * (largest squared spatial norm)
-    if (BF) delta += 0.00392f * hm::bitsf(p.rmax2_bits[1]);
+    // and the hi+lo split of the time coordinate leaves <= 2^-15 * x0*y0 (x0^2 <= rmax2)
+    if (BF) delta += 0.00392f * hm::bitsf(p.rmax2_bits[1]) + 3.1e-5f * rmax2;
     const float pre_f = p.u_hi + delta;              // candidate prefilter on u_f
     const float lo_f = p.u_lo - delta;               // u_f below this: canonical d < thr for sure
     const float zmax_f = 1.0f - delta;               // u_f at or below this: canonical u <= 1, d == 0
@@ -363,17 +376,19 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
     // ---- stationary A fragments: lane (r, h) keeps its operands of every k-step in registers ----
     float2 a[BF ? 1 : TM][BF ? 1 : NP];            // fp32 form: 2 operands (two k-steps) per group
     uint4 a16[BF ? TM : 1][BF ? NP : 1];           // bf16 form: 8 bf16 per 16-wide k-step
-    float nx0[BF ? TM : 1][16];                    // bf16 form: -x0 of the 16 rows this lane's accumulators hold
     if constexpr (BF) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const unsigned char* src = p.img16 + (int64_t)(i0w + 32 * tm + r) * RB16 + 16 * h;
 #pragma unroll
             for (int g = 0; g < NP; ++g) a16[tm][g] = *reinterpret_cast<const uint4*>(src + 32 * g);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = i0w + 32 * tm + (e & 3) + 8 * (e >> 2) + 4 * h;
-                nx0[tm][e] = -*reinterpret_cast<const float*>(p.img16 + (int64_t)row * RB16 + 32 * NG);
+            // stationary side of the time product: [hi, lo, hi, 0] -> [-hi, -hi, -lo, 0] (last 4 slots,
+            // held by the h = 1 half of the last k-step)
+            if (h == 1) {
+                const uint32_t z = a16[tm][NP - 1].z;
+                const uint32_t hi16 = z & 0xffffu, lo16 = z >> 16;
+                a16[tm][NP - 1].z = (hi16 | (hi16 << 16)) ^ 0x80008000u;
+                a16[tm][NP - 1].w = lo16 ^ 0x8000u;
             }
         }
     } else {
@@ -474,8 +489,6 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                 const char* bt = smem + buf * TILE_LDS + r * RB16 + 16 * h;
                 uint4 b0 = *reinterpret_cast<const uint4*>(bt);
                 uint4 b1 = *reinterpret_cast<const uint4*>(bt + 32 * RB16);
-                const float y0a = *reinterpret_cast<const float*>(smem + buf * TILE_LDS + r * RB16 + 32 * NG);
-                const float y0b = *reinterpret_cast<const float*>(smem + buf * TILE_LDS + (32 + r) * RB16 + 32 * NG);
 #pragma unroll
                 for (int g = 0; g < NP; ++g) {
                     uint4 n0 = b0, n1 = b1;
@@ -494,14 +507,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                     b0 = n0;
                     b1 = n1;
                 }
-                // time product in fp32: acc = S - x0*y0 (= -M), the convention of the fp32 form
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        acc[tm][0][e] = __builtin_fmaf(nx0[tm][e], y0a, acc[tm][0][e]);
-                        acc[tm][1][e] = __builtin_fmaf(nx0[tm][e], y0b, acc[tm][1][e]);
-                    }
+                // acc = S - x0*y0 (= -M): the time product came out of the last k-step's split slots
             } else {
                 // B fragments (optionally fetched one k-group ahead of the MFMAs that consume them)
                 const float* bt = reinterpret_cast<const float*>(smem + buf * TILE_LDS) + r * RS + 2 * h;
@@ -647,6 +653,10 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                         if (MODE == HM_MODE_ARGMIN) {
                             const unsigned long long wk = hm_wave_min_u64(wkey);
                             if (lane == 0) atomicMin(&p.ctr64[1], wk);
+                            // the slow path has drained the vector-memory queue anyway: refresh the
+                            // running key now (cheap here) so that the next tiles see the tight bound
+                            gk = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (wk < gk) gk = wk;
                         }
                     }
                 }
@@ -956,14 +966,8 @@ __global__ __launch_bounds__(64) void hm_merge_append_kernel(float* __restrict__
     const int CH = 2 * KS + 1;
     for (int cidx = lane; cidx < CH; cidx += 64) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (cidx == CH - 1) {
-            v.x = hm::fbits(so[0]);
-        } else {
-            float f[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { const int sidx = 8 * cidx + q; f[q] = sidx < d ? so[1 + sidx] : 0.0f; }
-            v = make_uint4(hm_pack_bf16(f[0], f[1]), hm_pack_bf16(f[2], f[3]), hm_pack_bf16(f[4], f[5]), hm_pack_bf16(f[6], f[7]));
-        }
+        if (cidx == CH - 1) v.x = hm::fbits(so[0]);
+        else v = hm_bf16_chunk(so + 1, so[0], d, KS, cidx);
         *reinterpret_cast<uint4*>(img16 + ((int64_t)new_row * CH + cidx) * 16) = v;
     }
 }
@@ -1118,7 +1122,7 @@ static const int kSupportedNG[] = {1, 2, 3, 4, 6, 8, 10, 13, 16, 20, 25, 28, 32}
 static const int kSupportedKS[] = {1, 2, 4, 7, 8};      // bf16 form: 16 spatial coordinates per k-step
 static int hm_pick_ks(int d)
 {
-    const int need = (d + 15) / 16;
+    const int need = (d + 4 + 15) / 16;        // d spatial slots + 4 slots for the split time coordinate
     for (int v : kSupportedKS)
         if (v >= need) return v;
     return -1;
