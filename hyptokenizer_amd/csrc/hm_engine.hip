@@ -51,7 +51,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_CHUNK_TILES 32          // fp32 form: column tiles per block (upper bound; shrunk for small tables)
 #endif
 #ifndef HM_CHUNK_TILES_BF16
-#define HM_CHUNK_TILES_BF16 128    // bf16 form: tiles are ~5x shorter, so blocks take more of them
+#define HM_CHUNK_TILES_BF16 48     // bf16 form: 128-column tiles, ~5x shorter per column than the fp32 form
 #endif
 #ifndef HM_TAIL_FRACTION
 #define HM_TAIL_FRACTION 0.15      // share of the work issued last in quarter-size chunks
@@ -85,6 +85,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 #ifndef HM_DIST_BF16
 #define HM_DIST_BF16 1             // bf16 form: tiles in flight ahead of the computed one (ring of DIST + 1 slots; deeper rings measured no gain)
+#endif
+#ifndef HM_TN_BF16
+#define HM_TN_BF16 4               // bf16 form: 128 partner rows per streamed tile (half the per-tile overhead)
 #endif
 #ifndef HM_WPB_BF16
 #define HM_WPB_BF16 4              // bf16 form: waves per block (all share each streamed 64-row tile)
@@ -291,12 +294,13 @@ __device__ __forceinline__ uint32_t hm_wave_incl_scan(uint32_t v, int lane)
 // Either way the result only selects survivors; every reported distance is re-evaluated with the
 // canonical arithmetic, and the bound `delta` on |u_f - u_c| widens every comparison accordingly.
 // TM = 32-row MFMA tiles per wave along the stationary rows (block = 4 waves = 128*TM rows).
-template <int NG, int SIGN, int MODE, int BF, int TM, int WPB>
+template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int TN>
 __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const ScanArgs p)
 {
+    constexpr int COLS = 32 * TN;                  // partner rows per streamed tile (TN 32-column MFMA tiles)
     constexpr int RS = hm_row_floats(NG);          // fp32 image: floats per row
     constexpr int RB16 = 32 * NG + 16;             // bf16 image: bytes per row (NG x 16 bf16 + [x0 fp32, pad])
-    constexpr int TILE_BYTES = BF ? HM_COLS_PER_TILE * RB16 : HM_COLS_PER_TILE * RS * 4;
+    constexpr int TILE_BYTES = BF ? COLS * RB16 : COLS * RS * 4;
     constexpr int NP = BF ? NG : NG + 1;           // k-steps: fp32: NG spatial groups + time; bf16: NG steps of 16
     constexpr int NPIECE = TILE_BYTES / 1024;      // 1 KiB pieces per 64-row tile (one per 16-byte chunk column)
     constexpr int TCH = RS / 4 - 1;                // fp32 image: chunk index of the time group
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
         ct0 = p.ctmin_b + slot_to_chunk(it % p.chunks_b) * p.ch_b;
         ct1 = ct0 + p.ch_b;
     }
-    if (ct0 < (rb * BLOCK_ROWS) / HM_COLS_PER_TILE) ct0 = (rb * BLOCK_ROWS) / HM_COLS_PER_TILE;   // left of the diagonal: no i < j
+    if (ct0 < (rb * BLOCK_ROWS) / COLS) ct0 = (rb * BLOCK_ROWS) / COLS;   // left of the diagonal: no i < j
     if (ct1 > p.nct) ct1 = p.nct;
     if (ct0 >= ct1) return;
 
@@ -464,13 +468,19 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
         int buf_next = buf + DIST;                           // slot of tile t + DIST = slot of tile t - 1:
         if (buf_next >= NBUF) buf_next -= NBUF;              // every wave left it at the previous barrier
 
-        const int j0 = ct * HM_COLS_PER_TILE;
-        const bool compute = wave_active && (j0 + 63 > i0w);
+        const int j0 = ct * COLS;
+        const bool compute = wave_active && (j0 + COLS - 1 > i0w);
 
-        if (!HM_DMA_INTERLEAVE || !compute || (BF ? NP < PPW : NP - 1 < PPW)) {
+        if (!HM_DMA_INTERLEAVE || !compute || (!BF && NP - 1 < PPW)) {
             if (has_next) dma_tile(ct_next, buf_next);
+        } else if (BF && NP < PPW) {
+            // more pieces than k-steps: the first PPW - NP go out ahead of the MFMA loop
+            if (has_next) {
+#pragma unroll
+                for (int q = NP; q < PPW; ++q) dma_piece(ct_next, buf_next, q * WPB + wave);
+            }
         }
-        f32x16 acc[TM][2];
+        f32x16 acc[TM][TN];
         if (compute) {
             // running best key of the argmin search, refreshed every 8th tile only: hipcc waits for
             // this vector load with vmcnt(0), which also drains the LDS-DMA ring.  A stale key only
@@ -480,35 +490,35 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[tm][tn][e] = 0.0f;
 
             if constexpr (BF) {
                 // bf16 prefilter: S = sum over the spatial coordinates, 16 per MFMA, fp32 accumulate
                 const char* bt = smem + buf * TILE_LDS + r * RB16 + 16 * h;
-                uint4 b0 = *reinterpret_cast<const uint4*>(bt);
-                uint4 b1 = *reinterpret_cast<const uint4*>(bt + 32 * RB16);
+                uint4 bc[TN], bn[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bc[tn] = *reinterpret_cast<const uint4*>(bt + 32 * tn * RB16);
 #pragma unroll
                 for (int g = 0; g < NP; ++g) {
-                    uint4 n0 = b0, n1 = b1;
                     if (g + 1 < NP) {
-                        n0 = *reinterpret_cast<const uint4*>(bt + 32 * (g + 1));
-                        n1 = *reinterpret_cast<const uint4*>(bt + 32 * RB16 + 32 * (g + 1));
-                    }
-                    if (HM_DMA_INTERLEAVE && g < PPW && has_next) dma_piece(ct_next, buf_next, g * WPB + wave);
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
-                                                                            __builtin_bit_cast(bf16x8, b0), acc[tm][0], 0, 0, 0);
-                        acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
-                                                                            __builtin_bit_cast(bf16x8, b1), acc[tm][1], 0, 0, 0);
+                        for (int tn = 0; tn < TN; ++tn) bn[tn] = *reinterpret_cast<const uint4*>(bt + 32 * tn * RB16 + 32 * (g + 1));
                     }
-                    b0 = n0;
-                    b1 = n1;
+                    if (HM_DMA_INTERLEAVE && g < PPW && g < NP && has_next) dma_piece(ct_next, buf_next, g * WPB + wave);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
+                                                                                 __builtin_bit_cast(bf16x8, bc[tn]), acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bc[tn] = bn[tn];
                 }
                 // acc = S - x0*y0 (= -M): the time product came out of the last k-step's split slots
             } else {
+                static_assert(BF || TN == 2, "the fp32 form is written for two 32-column tiles per streamed tile");
                 // B fragments (optionally fetched one k-group ahead of the MFMAs that consume them)
                 const float* bt = reinterpret_cast<const float*>(smem + buf * TILE_LDS) + r * RS + 2 * h;
 #if HM_PREFETCH_B
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
                         ext = SIGN ? __builtin_fmaxf(ext, acc[tm][tn][e]) : __builtin_fminf(ext, acc[tm][tn][e]);
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
             }
 
             if (__ballot(ext_u < bound_f) != 0ull) {
-                const bool full = rows_full && (j0 > i0w + WAVE_ROWS - 1) && (j0 + 63 < p.n);
+                const bool full = rows_full && (j0 > i0w + WAVE_ROWS - 1) && (j0 + COLS - 1 < p.n);
                 // -------- slow path: per-element predicates, evaluated twice (count, then write).
                 // The second evaluation runs on laundered copies of the bounds so that the compiler
                 // does not keep 64 predicates alive across the wave scan (that spills).
@@ -630,7 +640,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn)
+                    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) visit(acc[tm][tn][e], tm, tn, e, false);
 
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                            for (int tn = 0; tn < 2; ++tn)
+                            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                                 for (int e = 0; e < 16; ++e) visit(acc[tm][tn][e], tm, tn, e, true);
                         if (MODE == HM_MODE_ARGMIN) {
@@ -1296,35 +1306,35 @@ static Bounds hm_bounds(float thr, float c)
     return b;
 }
 
-template <int NG, int SIGN, int MODE, int BF, int TM, int WPB>
+template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int TN>
 static hipError_t hm_launch_scan_t(const ScanArgs& a, dim3 grid, hipStream_t s)
 {
-    const size_t tile_bytes = BF ? (size_t)HM_COLS_PER_TILE * (32 * NG + 16) : sizeof(float) * HM_COLS_PER_TILE * hm_row_floats(NG);
+    const size_t tile_bytes = BF ? (size_t)32 * TN * (32 * NG + 16) : sizeof(float) * 32 * TN * hm_row_floats(NG);
     const size_t ppw = (tile_bytes / 1024 + WPB - 1) / WPB;
     size_t lds = ((BF ? HM_DIST_BF16 : 1) + 1) * ppw * WPB * 1024;
     if (MODE == HM_MODE_HIST) lds += sizeof(uint32_t) * HM_HIST_BINS;
     static bool attr_set = false;    // per instantiation
     if (!attr_set && lds > 48 * 1024) {
-        hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(&hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB>),
+        hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(&hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, TN>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (st != hipSuccess) return st;
         attr_set = true;
     }
-    hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB>), grid, dim3(64 * WPB), lds, s, a);
+    hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, TN>), grid, dim3(64 * WPB), lds, s, a);
     return hipGetLastError();
 }
 
-template <int NG, int BF, int TM, int WPB>
+template <int NG, int BF, int TM, int WPB, int TN>
 static hipError_t hm_launch_scan_ng(int sign, int mode, const ScanArgs& a, dim3 grid, hipStream_t s)
 {
     if (sign) {
-        if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 1, HM_MODE_TOPK, BF, TM, WPB>(a, grid, s);
-        if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 1, HM_MODE_ARGMIN, BF, TM, WPB>(a, grid, s);
-        return hm_launch_scan_t<NG, 1, HM_MODE_HIST, BF, TM, WPB>(a, grid, s);
+        if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 1, HM_MODE_TOPK, BF, TM, WPB, TN>(a, grid, s);
+        if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 1, HM_MODE_ARGMIN, BF, TM, WPB, TN>(a, grid, s);
+        return hm_launch_scan_t<NG, 1, HM_MODE_HIST, BF, TM, WPB, TN>(a, grid, s);
     }
-    if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 0, HM_MODE_TOPK, BF, TM, WPB>(a, grid, s);
-    if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 0, HM_MODE_ARGMIN, BF, TM, WPB>(a, grid, s);
-    return hm_launch_scan_t<NG, 0, HM_MODE_HIST, BF, TM, WPB>(a, grid, s);
+    if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 0, HM_MODE_TOPK, BF, TM, WPB, TN>(a, grid, s);
+    if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 0, HM_MODE_ARGMIN, BF, TM, WPB, TN>(a, grid, s);
+    return hm_launch_scan_t<NG, 0, HM_MODE_HIST, BF, TM, WPB, TN>(a, grid, s);
 }
 
 // Which prefilter form a scan uses.  The bf16 form's error bound 0.00392 * max||x_s||^2 only costs
@@ -1341,28 +1351,28 @@ static hipError_t hm_launch_scan(const hm_engine* e, int mode, const ScanArgs& a
 {
     if (a.bf16) {
         switch (e->KS) {
-            case 1: return hm_launch_scan_ng<1, 1, HM_TM_BF16, HM_WPB_BF16>(e->sign_mode, mode, a, grid, s);
-            case 2: return hm_launch_scan_ng<2, 1, HM_TM_BF16, HM_WPB_BF16>(e->sign_mode, mode, a, grid, s);
-            case 4: return hm_launch_scan_ng<4, 1, HM_TM_BF16, HM_WPB_BF16>(e->sign_mode, mode, a, grid, s);
-            case 7: return hm_launch_scan_ng<7, 1, HM_TM_BF16, HM_WPB_BF16>(e->sign_mode, mode, a, grid, s);
-            case 8: return hm_launch_scan_ng<8, 1, HM_TM_BF16, HM_WPB_BF16>(e->sign_mode, mode, a, grid, s);
+            case 1: return hm_launch_scan_ng<1, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
+            case 2: return hm_launch_scan_ng<2, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
+            case 4: return hm_launch_scan_ng<4, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
+            case 7: return hm_launch_scan_ng<7, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
+            case 8: return hm_launch_scan_ng<8, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
         }
         return hipErrorInvalidValue;
     }
     switch (e->NG) {
-        case 1: return hm_launch_scan_ng<1, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 2: return hm_launch_scan_ng<2, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 3: return hm_launch_scan_ng<3, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 4: return hm_launch_scan_ng<4, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 6: return hm_launch_scan_ng<6, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 8: return hm_launch_scan_ng<8, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 10: return hm_launch_scan_ng<10, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 13: return hm_launch_scan_ng<13, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 16: return hm_launch_scan_ng<16, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 20: return hm_launch_scan_ng<20, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 25: return hm_launch_scan_ng<25, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 28: return hm_launch_scan_ng<28, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
-        case 32: return hm_launch_scan_ng<32, 0, HM_TM_F32, 4>(e->sign_mode, mode, a, grid, s);
+        case 1: return hm_launch_scan_ng<1, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 2: return hm_launch_scan_ng<2, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 3: return hm_launch_scan_ng<3, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 4: return hm_launch_scan_ng<4, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 6: return hm_launch_scan_ng<6, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 8: return hm_launch_scan_ng<8, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 10: return hm_launch_scan_ng<10, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 13: return hm_launch_scan_ng<13, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 16: return hm_launch_scan_ng<16, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 20: return hm_launch_scan_ng<20, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 25: return hm_launch_scan_ng<25, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 28: return hm_launch_scan_ng<28, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 32: return hm_launch_scan_ng<32, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1379,11 +1389,12 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     a.img16 = e->img16;
     a.bf16 = hm_use_bf16(e) ? 1 : 0;
     const int block_rows = a.bf16 ? 32 * HM_TM_BF16 * HM_WPB_BF16 : 128 * HM_TM_F32;
+    const int cols = a.bf16 ? 32 * HM_TN_BF16 : 64;              // partner rows per streamed tile
     a.n = (int)e->n;
     a.row_begin = (int)row_begin;
     a.row_end = (int)row_end;
     a.rb_first = (int)(row_begin / block_rows);
-    a.nct = (int)((e->n + HM_COLS_PER_TILE - 1) / HM_COLS_PER_TILE);
+    a.nct = (int)((e->n + cols - 1) / cols);
     a.u_hi = b.u_hi;
     a.u_lo = b.u_lo;
     a.thr_pos = b.thr_pos;
@@ -1398,7 +1409,7 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     a.rmax2_bits = e->d_rmax2;
     const int rb_last = (int)((row_end - 1) / block_rows);
     const int nrb = rb_last - a.rb_first + 1;
-    const int tiles_per_rb = block_rows / HM_COLS_PER_TILE;                  // diagonal advance per row block
+    const int tiles_per_rb = block_rows / cols;                              // diagonal advance per row block (>= 1)
     // column tiles per block: amortise the stationary-row load, but keep enough blocks in flight
     int ch = a.bf16 ? HM_CHUNK_TILES_BF16 : HM_CHUNK_TILES;
     while (ch > 4 && (int64_t)nrb * ((a.nct + ch - 1) / ch) < 1024) ch >>= 1;
