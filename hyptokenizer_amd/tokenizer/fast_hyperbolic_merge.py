@@ -81,40 +81,86 @@ class AdaptiveMergeCache:
     """Sorted candidate cache (reference ``:63-133``): ``add_batch`` = concat + stable sort +
     truncate to ``max_size``; ``get_best(n)`` pops the first n.  ``hit_count`` only records pairs
     that were actually served (the reference also stores a zero for every candidate ever seen,
-    which has no effect on ``get_stats``)."""
+    which has no effect on ``get_stats``).
+
+    A refresh hands over up to ``max_size`` sorted candidates as arrays (``CandidateList``); they
+    stay arrays and become ``MergeCandidate`` objects only when popped or when ``candidates`` is
+    read, so a refresh does not build 10 000 Python objects that are mostly never looked at."""
 
     def __init__(self, max_size: int = 10000):
         self.max_size = max_size
-        self.candidates: List[MergeCandidate] = []
+        self._list: List[MergeCandidate] = []     # materialised entries (always in front of the arrays)
+        self._arr = None                          # (d, i, j) arrays of not-yet-materialised entries
+        self._pos = 0
         self.hit_count: Dict[Tuple[int, int], int] = {}
         self.miss_count: int = 0
-        self._hits = 0                      # running sum(hit_count.values())
+        self._hits = 0                            # running sum(hit_count.values())
+
+    # -- the reference's public attribute -------------------------------------------------------
+    @property
+    def candidates(self) -> List[MergeCandidate]:
+        self._materialise_all()
+        return self._list
+
+    @candidates.setter
+    def candidates(self, value) -> None:
+        self._list = list(value)
+        self._arr = None
+        self._pos = 0
+
+    def _pending(self) -> int:
+        return 0 if self._arr is None else len(self._arr[0]) - self._pos
+
+    def __len__(self) -> int:
+        return len(self._list) + self._pending()
+
+    def _take(self, n: int) -> List[MergeCandidate]:
+        """materialise the next n array entries"""
+        if self._arr is None or n <= 0:
+            return []
+        d, i, j = self._arr
+        hi = min(self._pos + n, len(d))
+        out = [MergeCandidate(float(a), int(b), int(c))
+               for a, b, c in zip(d[self._pos:hi].tolist(), i[self._pos:hi].tolist(), j[self._pos:hi].tolist())]
+        self._pos = hi
+        if self._pos >= len(d):
+            self._arr, self._pos = None, 0
+        return out
+
+    def _materialise_all(self) -> None:
+        if self._arr is not None:
+            self._list = self._list + self._take(self._pending())
 
     def add_batch(self, new_candidates) -> None:
-        if isinstance(new_candidates, CandidateList):
-            fresh = new_candidates[: self.max_size]
-        else:
-            fresh = list(new_candidates)
+        if isinstance(new_candidates, CandidateList) and len(self) == 0:
+            k = min(self.max_size, new_candidates.stored)
+            self._list = []
+            self._arr = (new_candidates._d[:k], new_candidates._i[:k], new_candidates._j[:k]) if k else None
+            self._pos = 0
+            return
+        fresh = new_candidates[: self.max_size] if isinstance(new_candidates, CandidateList) else list(new_candidates)
         merged = self.candidates + fresh
         merged.sort()                       # stable, by distance only
         self.candidates = merged[: self.max_size]
 
     def get_best(self, n: int = 1) -> List[MergeCandidate]:
-        if not self.candidates:
+        if len(self) == 0:
             self.miss_count += 1
             return []
-        best = self.candidates[:n]
+        best = self._list[:n]
+        self._list = self._list[n:]
+        if len(best) < n:
+            best = best + self._take(n - len(best))
         for cand in best:
             key = (cand.token_i, cand.token_j)
             self.hit_count[key] = self.hit_count.get(key, 0) + 1
         self._hits += len(best)
-        self.candidates = self.candidates[n:]
         return best
 
     def get_stats(self) -> Dict[str, Any]:
         hits = self._hits
         return {
-            "size": len(self.candidates),
+            "size": len(self),
             "max_size": self.max_size,
             "hit_count": hits,
             "miss_count": self.miss_count,
