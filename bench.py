@@ -178,6 +178,25 @@ def main() -> None:
         fast = {"merges_per_s": (len(ftok.merge_history) - 101) / tf, "steps": fsteps - 101,
                 "note": "FastHyperbolicTokenizer.optimize_merges: cache of 10000, one exact top-k search per ~101 steps"}
 
+    # incremental figure (SURVEY 8(d) variant (ii)): same merges, nearest pair maintained with one
+    # row-vs-all pass per step instead of a full search; the merge sequence is checked against the
+    # timed run's
+    incr = None
+    if rank == 0 or world > 1:
+        isteps = max(args.steps + args.warmup, 2)
+        itok = HyperbolicTokenizer(vocab, torch.nn.Parameter(X), curvature=CURV, merge_threshold=THR, device=device,
+                                   max_vocab_size=V + isteps + 64, sign_convention="lorentz", shard=shard, incremental=True)
+        itok._get_engine()
+        itok.optimize_merges(steps=1, log_every=10 ** 9)           # the one full search
+        barrier()
+        ti0 = time.perf_counter()
+        itok.optimize_merges(steps=isteps - 1, log_every=10 ** 9)
+        barrier()
+        ti = time.perf_counter() - ti0
+        incr = {"merges_per_s": (len(itok.merge_history) - 1) / ti, "steps": isteps - 1,
+                "same_merges_as_full_search": itok.merge_history == tok.merge_history[:len(itok.merge_history)],
+                "note": "HyperbolicTokenizer(incremental=True): one full search, then one row-vs-all reduction per merge"}
+
     fp32_form = None
     if rank == 0 and world == 1 and os.environ.get("HM_SCAN_PRECISION", "auto") != "f32":
         from hyptokenizer_amd.engine import MergeEngine
@@ -241,6 +260,7 @@ def main() -> None:
                          "note": "flops = N(N-1)(d+1) algorithmic (triangle); peak = dense MFMA peak of the prefilter's dtype"},
             "roofline_fp32_form": fp32_form,
             "fast_path": fast,
+            "incremental": incr,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X.numpy(), device)

@@ -24,7 +24,7 @@ SIGN_REFERENCE, SIGN_LORENTZ = 0, 1
 EXPORTED_SYMBOLS = (
     "hm_abi_version", "hm_last_error", "hm_engine_create", "hm_engine_destroy", "hm_set_table",
     "hm_update_rows", "hm_rows", "hm_pairwise_argmin", "hm_pairwise_argmin_dev", "hm_pairwise_topk", "hm_pairwise_candidates",
-    "hm_row_vs_all", "hm_pair_distance", "hm_midpoint_batch", "hm_merge_append", "hm_batch_distance",
+    "hm_row_vs_all", "hm_row_argmin", "hm_pair_distance", "hm_midpoint_batch", "hm_merge_append", "hm_batch_distance",
     "hm_rows_minkowski", "hm_rows_distance", "hm_rows_log_map", "hm_rows_exp_map", "hm_rows_project",
     "hm_last_scan_stats", "hm_scan_totals",
 )
@@ -76,6 +76,7 @@ def load() -> C.CDLL:
     L.hm_pairwise_topk.argtypes = [vp, f32, f32, i64, i64, i64, vp, vp, vp, pi64, pi64, vp]
     L.hm_pairwise_candidates.argtypes = [vp, f32, f32, i64, i64, i64, vp, vp, vp, pi64, vp]
     L.hm_row_vs_all.argtypes = [vp, i64, i64, f32, vp, vp]
+    L.hm_row_argmin.argtypes = [vp, i64, i64, f32, f32, pf32, pi32, pi32, pi32, vp]
     L.hm_pair_distance.argtypes = [vp, vp, vp, i64, f32, vp, vp]
     L.hm_midpoint_batch.argtypes = [vp, vp, vp, vp, i64, f32, vp, vp]
     L.hm_merge_append.argtypes = [vp, i32, i32, f32, f32, vp, i64, i64, vp]

@@ -759,6 +759,26 @@ __global__ __launch_bounds__(HM_ARGMIN_BLOCKS) void hm_post_argmin_final_kernel(
     }
 }
 
+// K3 fused with a min-reduction: canonical distance from image row `row` to every row i < n_partners,
+// smallest (d bits, i) with d < thr per block -> parts (pair = (i, row), i < row).
+__global__ __launch_bounds__(256) void hm_row_argmin_kernel(const float* __restrict__ img, int RS, int d, int sign_mode, int64_t row,
+                                                            int64_t n_partners, float sqrt_c, float thr, ArgminPart* __restrict__ parts)
+{
+    __shared__ uint32_t s0[256], s1[256], s2[256];
+    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_partners; i += (int64_t)gridDim.x * 256) {
+        if (i == row) continue;
+        const int64_t lo = i < row ? i : row, hi = i < row ? row : i;
+        const float dd = hm::dist_from_u(hm_img_u(img, RS, d, lo, hi, sign_mode), sqrt_c);
+        if (dd < thr) {
+            const uint32_t db = hm::fbits(dd);
+            if (hm_key_less(db, (uint32_t)lo, (uint32_t)hi, b0, b1, b2)) { b0 = db; b1 = (uint32_t)lo; b2 = (uint32_t)hi; }
+        }
+    }
+    hm_block_min_key(b0, b1, b2, s0, s1, s2);
+    if (threadIdx.x == 0) { parts[blockIdx.x].dbits = b0; parts[blockIdx.x].i = b1; parts[blockIdx.x].j = b2; parts[blockIdx.x].pad = 0; }
+}
+
 // entries {bits(u_f'), i, j, sure} -> {dbits | 0xffffffff, i, j, bits(u_c')} with the canonical
 // distance; counts[0] valid, counts[1] valid & !sure, counts[3] sure & !valid (margin violated: must be 0)
 __global__ void hm_post_distance_kernel(uint4* __restrict__ ent, const uint32_t* __restrict__ ctr, uint32_t cap,
@@ -1838,6 +1858,32 @@ extern "C" int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, floa
     hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
                        row, n, sqrtf(c), e->sign_mode, d_out_dev);
     HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_row_argmin(hm_engine* e, int64_t row, int64_t n_partners, float c, float thr, float* d, int32_t* i, int32_t* j,
+                             int32_t* found, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_row_argmin: engine is NULL");
+    if (!d || !i || !j || !found) return hm_fail(e, HM_E_ARG, "hm_row_argmin: NULL output pointer");
+    if (row < 0 || row >= e->n || n_partners < 0 || n_partners > e->n || !(c > 0.0f))
+        return hm_fail(e, HM_E_ARG, "hm_row_argmin: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    *found = 0; *d = 0.f; *i = -1; *j = -1;
+    if (!(thr > 0.0f) || n_partners == 0) return HM_OK;
+    HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));     // ctr[0] = 0: the final kernel's overflow test stays quiet
+    hipLaunchKernelGGL(hm_row_argmin_kernel, dim3(HM_ARGMIN_BLOCKS), dim3(256), 0, s, e->img, e->RS, e->d, e->sign_mode, row,
+                       n_partners, sqrtf(c), thr, e->d_parts);
+    HM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec, e->d_ctr, e->ent_cap);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
+    HM_HIP(hipStreamSynchronize(s));
+    if (e->h->rec.found == 1u) {
+        union { uint32_t u; float f; } cv; cv.u = e->h->rec.dbits;
+        *found = 1; *d = cv.f; *i = (int32_t)e->h->rec.i; *j = (int32_t)e->h->rec.j;
+    }
     return HM_OK;
 }
 

@@ -108,6 +108,15 @@ class MergeEngine:
             return None
         return float(d.value), int(i.value), int(j.value)
 
+    def row_argmin(self, row: int, n_partners: int, c: float, thr: float) -> Optional[Tuple[float, int, int]]:
+        """Nearest partner of `row` among rows [0, n_partners): (d, i, j) with i < j, or None."""
+        d, i, j, f = C.c_float(0), C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
+        self._chk(self._L.hm_row_argmin(self._h, int(row), int(n_partners), float(c), float(thr),
+                                        C.byref(d), C.byref(i), C.byref(j), C.byref(f), self._stream()))
+        if not f.value:
+            return None
+        return float(d.value), int(i.value), int(j.value)
+
     def argmin_into(self, c: float, thr: float, row_begin: int, row_end: int, rec: torch.Tensor) -> None:
         """Asynchronous nearest-pair search: writes int32[4] {found, bits(d), i, j} into the device
         tensor `rec` on the current stream (found = 2: buffer overflow, use ``argmin``)."""

@@ -14,7 +14,10 @@ Additive keyword-only arguments: ``sign_convention`` ("reference" = arithmetic a
 default; "lorentz" = sign-corrected) and ``engine`` (an object with the
 ``MergeEngine`` interface; tests inject an oracle-backed double, the product never does) and
 ``shard`` (a ``hyptokenizer_amd.sharding.ShardContext``: the candidate search is row-sharded over
-the ranks of a process group and every rank applies the same merge to its replica).
+the ranks of a process group and every rank applies the same merge to its replica), and
+``incremental`` (maintain the nearest pair across steps instead of re-searching: rows are only ever
+appended, so after a merge the global minimum is ``min(previous minimum, nearest partner of the new
+row)`` -- one row-vs-all pass per step, same pairs, same distances).
 The FAISS pre-filter of the reference (``:203-244``, ``:593-625``) is replaced by the exact GPU
 search and never used: ``FAISS_AVAILABLE`` is always False here.
 """
@@ -75,6 +78,7 @@ class HyperbolicTokenizer:
         sign_convention: str = "reference",
         engine=None,
         shard=None,
+        incremental: bool = False,
     ):
         if device is None:
             device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -101,6 +105,8 @@ class HyperbolicTokenizer:
         self._engine = engine
         self._engine_key = None       # (table identity, version, rows) the engine image was built from
         self.shard = shard            # hyptokenizer_amd.sharding.ShardContext: row-sharded search over ranks
+        self.incremental = bool(incremental)
+        self._inc = None              # incremental search state: (threshold, rows covered, best (d, i, j) | None)
 
     # ------------------------------------------------------------------------------------------
     # engine plumbing
@@ -118,6 +124,7 @@ class HyperbolicTokenizer:
         if key != self._engine_key:
             self._engine.set_table(self.embeddings.data, self.current_vocab_size)
             self._engine_key = key
+            self._inc = None          # the table changed under the maintained minimum
         return self._engine
 
     def _table_key(self):
@@ -152,7 +159,9 @@ class HyperbolicTokenizer:
 
     def _best_candidate(self) -> Optional[Tuple[int, int, float]]:
         """``sorted(candidates, key=distance)[0]`` without building the list."""
-        if self.shard is not None:
+        if self.incremental:
+            hit = self._best_incremental()
+        elif self.shard is not None:
             from ..sharding import sharded_argmin
             hit = sharded_argmin(self._get_engine(), self.shard, self.curvature, self._search_threshold())
         else:
@@ -161,6 +170,32 @@ class HyperbolicTokenizer:
             return None
         d, i, j = hit
         return i, j, d
+
+    def _best_incremental(self) -> Optional[Tuple[float, int, int]]:
+        """The same ``(d, i, j)`` the full search returns, maintained across steps.  The candidate
+        set only grows (``_merge_tokens`` appends row ``n`` and removes nothing, reference
+        ``:326-351``), so ``min`` over it is a running minimum: one full search when the state is
+        new or stale (table edited, threshold changed), then one row-vs-all reduction per appended
+        row.  The key order (d, i, j) is the full search's (distance, then row-major)."""
+        eng = self._get_engine()                  # drops self._inc when the table was edited
+        n, thr = self.current_vocab_size, self._search_threshold()
+        st = self._inc
+        if st is None or st[0] != thr or st[1] > n:
+            if self.shard is not None:
+                from ..sharding import sharded_argmin
+                best = sharded_argmin(eng, self.shard, self.curvature, thr)
+            else:
+                best = eng.argmin(self.curvature, thr)
+            rows = n
+        else:
+            _, rows, best = st
+            for r in range(rows, n):              # every rank does this redundantly: no exchange needed
+                cand = eng.row_argmin(r, r, self.curvature, thr)
+                if cand is not None and (best is None or cand < best):
+                    best = cand
+            rows = n
+        self._inc = (thr, rows, best)
+        return best
 
     def _is_valid_merge(self, token_i: str, token_j: str) -> bool:
         return True               # reference ``:293-307``

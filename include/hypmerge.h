@@ -98,6 +98,14 @@ int hm_pairwise_candidates(hm_engine* e, float c, float thr, int64_t row_begin, 
  * No reference equivalent (incremental maintenance). */
 int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, float* d_out_dev, void* stream);
 
+/* K3 + reduction: the nearest partner of image row `row` among rows [0, n_partners) (itself
+ * excluded): smallest (d, min(i,row), max(i,row)) with d < thr, in host memory.  Lets a caller
+ * maintain the global nearest pair incrementally: rows are only ever appended, so after
+ * a merge the global minimum is min(previous minimum, nearest partner of the new row).
+ * No reference equivalent (the reference recomputes everything, hyperbolic_merge.py:247-269). */
+int hm_row_argmin(hm_engine* e, int64_t row, int64_t n_partners, float c, float thr, float* d, int32_t* i,
+                  int32_t* j, int32_t* found, void* stream);
+
 /* K5: gathered pair distances on the image: out_dev[t] = d(row I[t], row J[t]).
  * Replaces: distance(...).item() loops (_compute_distance_statistics fast...:448-455,
  * n<=100 branch hyperbolic_merge.py:270-289). */

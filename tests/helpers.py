@@ -83,6 +83,17 @@ class OracleEngine:
     def row_vs_all(self, row, n, c):
         return O.row_vs_all(self.X, n, row, float(c), self.sign_mode)
 
+    def row_argmin(self, row, n_partners, c, thr):
+        d = np.asarray(O.row_vs_all(self.X, max(n_partners, row + 1), row, float(c), self.sign_mode), np.float32)[:n_partners]
+        best = None
+        for i in np.nonzero(d < np.float32(thr))[0].tolist():
+            if i == row:
+                continue
+            key = (float(d[i]), min(i, row), max(i, row))
+            if best is None or key < best:
+                best = key
+        return best
+
     def scan_stats(self):
         return {"scan_ms": 0.0, "pairs": 0, "emitted": 0, "passes": 0}
 

@@ -154,6 +154,51 @@ def test_full_size_properties(V, d):
     assert (c2[1], c2[2]) == (row, V)
 
 
+@pytest.mark.parametrize("mode", ["reference", "lorentz"])
+def test_row_argmin_matches_oracle(oracle, mode):
+    """K3 + reduction against the oracle's row-vs-all distances: nearest partner, threshold, ties"""
+    from hyptokenizer_amd.engine import MergeEngine
+    V, d = 3000, 40
+    X = lorentz_table(V, d, seed=5, scale=0.1)
+    X[77] = X[2100]                                      # an exact duplicate: distance 0 tie-breaks by index
+    Xn = X.numpy()
+    eng = MergeEngine(V, d + 1, mode)
+    eng.set_table(X.cuda(), V)
+    for row, npart in [(2999, 2999), (2100, 2100), (77, 3000), (0, 3000), (1500, 10), (5, 0)]:
+        dist = np.asarray(oracle.row_vs_all(Xn, max(npart, row + 1), row, 1.0, MODES[mode]), np.float32)[:npart]
+        for thr in (0.3, 1.5, 1e9):
+            want = None
+            for i in np.nonzero(dist < np.float32(thr))[0].tolist():
+                if i != row:
+                    key = (int(bits([dist[i]])[0]), min(i, row), max(i, row))
+                    want = key if want is None or key < want else want
+            got = eng.row_argmin(row, npart, 1.0, thr)
+            assert (got is None) == (want is None), (row, npart, thr)
+            if got is not None:
+                assert (int(bits([got[0]])[0]), got[1], got[2]) == want, (row, npart, thr)
+
+
+@pytest.mark.parametrize("V,d,thr", [(6000, 64, 0.6), (150, 16, 1.0), (95, 16, 1.0)])
+def test_incremental_loop_equals_full_search(V, d, thr):
+    """incremental=True merges the same pairs into the same rows as a full search every step
+    (95 rows: the loop crosses the reference's n <= 100 double-compare branch)"""
+    from hyptokenizer_amd.tokenizer.hyperbolic_merge import HyperbolicTokenizer
+    X = lorentz_table(V, d, seed=11, scale=0.05)
+    runs = []
+    for inc in (False, True):
+        tok = HyperbolicTokenizer(vocab=cjk_vocab(V), embeddings=torch.nn.Parameter(X.clone()), merge_threshold=thr,
+                                  device=torch.device("cuda"), max_vocab_size=V + 400, sign_convention="lorentz", incremental=inc)
+        tok.optimize_merges(steps=120, log_every=10 ** 9)
+        tok.embeddings.data[3] = tok.embeddings.data[V - 1]       # an edit of the table invalidates the running minimum
+        tok.refresh_engine()
+        tok.optimize_merges(steps=40, log_every=10 ** 9)
+        runs.append(tok)
+    a, b = runs
+    assert a.merge_history == b.merge_history and len(a.merge_history) == 160
+    n = a.current_vocab_size
+    assert torch.equal(a.embeddings.data[:n].view(torch.int32), b.embeddings.data[:n].view(torch.int32))
+
+
 def test_device_record_and_world1_nccl_shard(oracle):
     """asynchronous argmin record (multi-GPU exchange path) equals the host form; a 1-rank RCCL
     process group drives the sharded tokenizer through the same code the N-GPU run uses"""

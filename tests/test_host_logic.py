@@ -66,6 +66,14 @@ def check_sequences(golden_dir, mode, engine_factory, device):
     assert nan_equal_close(rows, z["std_rows"], 1e-5)
     assert tok.merge_threshold == meta["std_threshold"]
     assert tok.vocab[V:] == meta["std_vocab_tail"]
+    # incremental maintenance of the nearest pair: same pairs, same rows, bit for bit
+    seed_all(42)
+    itok = make(HyperbolicTokenizer, X, mode, engine_factory=engine_factory, device=device, incremental=True)
+    ipairs = record(itok)
+    itok.optimize_merges(steps=meta["std_steps"], log_every=10 ** 9, parallel_eval=False)
+    assert np.array_equal(np.array(ipairs, np.int32).reshape(-1, 2), z["std_pairs"])
+    irows = itok.embeddings.data[V:itok.current_vocab_size]
+    assert torch.equal(irows.view(torch.int32).cpu(), tok.embeddings.data[V:tok.current_vocab_size].view(torch.int32).cpu())
     # fast tokenizer, two logging cadences (log steps consume the Python RNG)
     for key in ("fast", "fastlog"):
         seed_all(42)
@@ -170,6 +178,45 @@ def test_cpu_search_raises_without_engine():
     ftok = make(FastHyperbolicTokenizer, X, "lorentz")
     with pytest.raises(HypMergeUnavailable):
         ftok.optimize_merges(steps=1)
+
+
+def test_incremental_state_invalidation():
+    """the running minimum is recomputed when the threshold moves, the table is edited, or the
+    search crosses the reference's n <= 100 compare branch; otherwise one row pass per step"""
+    from hyptokenizer_amd.synthetic import lorentz_table
+    X = lorentz_table(97, 12, seed=3, scale=0.05).numpy()
+    calls = {"full": 0, "row": 0}
+
+    class Counting(OracleEngine):
+        def argmin(self, *a, **k):
+            calls["full"] += 1
+            return super().argmin(*a, **k)
+
+        def row_argmin(self, *a, **k):
+            calls["row"] += 1
+            return super().row_argmin(*a, **k)
+
+    full = make(HyperbolicTokenizer, X, "lorentz", thr=0.7, engine_factory=OracleEngine)
+    inc = make(HyperbolicTokenizer, X, "lorentz", thr=0.7, engine_factory=Counting, incremental=True)
+    for tok in (full, inc):
+        tok.optimize_merges(steps=3, log_every=10 ** 9)          # 97 -> 100 rows
+    assert calls == {"full": 1, "row": 2}
+    for tok in (full, inc):
+        tok.optimize_merges(steps=3, log_every=10 ** 9)          # crosses n = 100: threshold form changes once
+    assert calls == {"full": 2, "row": 4}                       # 0.7 rounds differently in the two compare forms
+    before = dict(calls)
+    for tok in (full, inc):
+        tok.merge_threshold = 0.6
+        tok.optimize_merges(steps=2, log_every=10 ** 9)
+    assert calls["full"] == before["full"] + 1 and calls["row"] == before["row"] + 1
+    for tok in (full, inc):
+        tok.embeddings.data[5] = tok.embeddings.data[50]
+        tok.refresh_engine()
+        tok.optimize_merges(steps=2, log_every=10 ** 9)
+    assert calls["full"] == before["full"] + 2
+    assert full.merge_history == inc.merge_history and len(inc.merge_history) == 10
+    n = inc.current_vocab_size
+    assert torch.equal(full.embeddings.data[:n].view(torch.int32), inc.embeddings.data[:n].view(torch.int32))
 
 
 def test_cache_semantics():
