@@ -51,7 +51,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_CHUNK_TILES 32          // fp32 form: column tiles per block (upper bound; shrunk for small tables)
 #endif
 #ifndef HM_CHUNK_TILES_BF16
-#define HM_CHUNK_TILES_BF16 48     // bf16 form: 128-column tiles, ~5x shorter per column than the fp32 form
+#define HM_CHUNK_TILES_BF16 96     // bf16 form: 64-column tiles, ~5x shorter per column than the fp32 form
 #endif
 #ifndef HM_TAIL_FRACTION
 #define HM_TAIL_FRACTION 0.15      // share of the work issued last in quarter-size chunks
@@ -80,14 +80,49 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef HM_TM_F32
 #define HM_TM_F32 1                // fp32 form: 32-row MFMA tiles per wave (block = 128 rows, 2 blocks per CU)
 #endif
+// timing diagnostics only (wrong results): drop one ingredient of the bf16 scan loop
+#ifndef HM_DIAG_NO_DMA
+#define HM_DIAG_NO_DMA 0
+#endif
+#ifndef HM_DIAG_NO_EPI
+#define HM_DIAG_NO_EPI 0
+#endif
+#ifndef HM_DIAG_NO_BARRIER
+#define HM_DIAG_NO_BARRIER 0
+#endif
+#ifndef HM_DIAG_NO_LDS
+#define HM_DIAG_NO_LDS 0
+#endif
+#ifndef HM_DIAG_SAME_TILES
+#define HM_DIAG_SAME_TILES 0
+#endif
+#ifndef HM_DIAG_NO_SLOW
+#define HM_DIAG_NO_SLOW 0
+#endif
+#ifndef HM_DIAG_NO_MFMA
+#define HM_DIAG_NO_MFMA 0
+#endif
+#ifndef HM_PERSIST
+#define HM_PERSIST 0               // experiment (off): bf16 form, one resident block per slot walks an equal share of the
+                                   // tile sequence -- no launch tail, but measured 50 % slower than the chunked grid
+#endif
+#ifndef HM_PERSIST_BLOCKS_PER_CU
+#define HM_PERSIST_BLOCKS_PER_CU 2
+#endif
+#ifndef HM_SETTLE_PROLOGUE
+#define HM_SETTLE_PROLOGUE 1
+#endif
+#ifndef HM_DMA_GROUPED
+#define HM_DMA_GROUPED 1           // bf16 form: LDS-DMA pieces issued four per statement, unconditionally (see hm_dma_group)
+#endif
 #ifndef HM_TM_BF16
-#define HM_TM_BF16 1               // bf16 form: 32-row MFMA tiles per wave
+#define HM_TM_BF16 2               // bf16 form: 64 stationary rows per wave (each LDS fragment read feeds two MFMAs)
 #endif
 #ifndef HM_DIST_BF16
 #define HM_DIST_BF16 1             // bf16 form: tiles in flight ahead of the computed one (ring of DIST + 1 slots; deeper rings measured no gain)
 #endif
 #ifndef HM_TN_BF16
-#define HM_TN_BF16 4               // bf16 form: 128 partner rows per streamed tile (half the per-tile overhead)
+#define HM_TN_BF16 2               // bf16 form: 64 partner rows per streamed tile
 #endif
 #ifndef HM_WPB_BF16
 #define HM_WPB_BF16 4              // bf16 form: waves per block (all share each streamed 64-row tile)
@@ -129,6 +164,12 @@ struct ScanArgs {
     // its 4 MiB L2 -- and the mirrored pairs give every XCD the same share of the triangle.
     int swizzle;
     int skip_empty, rows_a, m_a, rows_b, m_b;   // triangular item numbering (no empty blocks)
+    // persistent decomposition (bf16 form, TOPK / ARGMIN): the tiles right of the diagonal of row blocks
+    // rb_first .. rb_first + p_nrb - 1, in row-major order, form one sequence of p_total tiles; block b of
+    // p_grid resident blocks walks the share [b * p_total / p_grid, (b + 1) * p_total / p_grid) and reloads
+    // its stationary rows whenever the share crosses into the next row block.
+    long long p_total;
+    int p_nrb, p_grid;
     float u_hi;             // candidate prefilter: u < u_hi
     float u_lo;             // surely-below-threshold bound: u' < u_lo
     uint32_t cut_bits;      // emit when bits(u') <= cut_bits (or not sure)
@@ -288,6 +329,67 @@ __device__ __forceinline__ uint32_t hm_wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
+// Bound on |u_f - u_c| between the MFMA prefilter value and the canonical value of the same pair
+// (gamma_n bounds on both roundings, |terms| <= rmax2).  `kterms` = fp32 form: floats per image row;
+// bf16 form: 16 * k-steps.  bf16 operands: each spatial product carries <= 2 * 2^-9 (+ 2^-18) relative
+// error, so the sum is off by <= 2^-8 (1 + 2^-9) ||x_s|| ||y_s|| <= 0.00392 * (largest squared spatial
+// norm); the hi+lo split of the time coordinate leaves <= 2^-15 * x0*y0 (x0^2 <= rmax2).
+__device__ __forceinline__ float hm_scan_delta(bool bf, int kterms, const uint32_t* rmax2_bits)
+{
+    const float rmax2 = hm::bitsf(rmax2_bits[0]);
+    float delta = ((float)(kterms + 8) * 1.1920929e-07f) * rmax2 * 1.0001f;
+    if (bf) delta += 0.00392f * hm::bitsf(rmax2_bits[1]) + 3.1e-5f * rmax2;
+    return delta;
+}
+
+// Seed of the argmin search's running key, kept on the device between searches: the key of the last
+// nearest pair found.  While rows are only appended that pair still exists, so its key bounds the next
+// search from its first tile on (without it the bound is loose until some wave happens to reach a near
+// pair).  `valid` is cleared whenever an existing row changes.
+struct ArgminSeed { unsigned long long key; uint32_t i, valid; };
+
+__global__ void hm_seed_init_kernel(const ArgminSeed* __restrict__ seed, unsigned long long* __restrict__ ctr64, int row_begin, int row_end)
+{
+    const bool use = seed->valid != 0u && (int)seed->i >= row_begin && (int)seed->i < row_end;
+    ctr64[0] = ~0ull;
+    ctr64[1] = use ? seed->key : ~0ull;
+}
+
+// CNT (1..4) consecutive 1 KiB LDS-DMA pieces in one statement: one M0 write; the immediate offset of
+// global_load_lds applies to the global and to the LDS address alike, so the pieces share both bases.
+template <int CNT>
+__device__ __forceinline__ void hm_dma_group(const char* src, uint32_t dst)
+{
+    uint32_t keep;
+    if constexpr (CNT == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else if constexpr (CNT == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else if constexpr (CNT == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+// PIECES consecutive pieces starting at piece index FIRST, four per statement
+template <int PIECES, int FIRST = 0>
+__device__ __forceinline__ void hm_dma_run(const char* src, uint32_t dst)
+{
+    if constexpr (FIRST < PIECES) {
+        hm_dma_group<(PIECES - FIRST < 4 ? PIECES - FIRST : 4)>(src + FIRST * 1024, dst + FIRST * 1024u);
+        hm_dma_run<PIECES, FIRST + 4>(src, dst);
+    }
+}
+
 // BF = 0: exact fp32 prefilter (v_mfma_f32_32x32x2_f32 on the fp32 image; NG = groups of 4 spatial
 //         coordinates).  BF = 1: bf16 prefilter (v_mfma_f32_32x32x16_bf16 on the bf16 image, spatial
 //         part only; NG = k-steps of 16; the time product x0*y0 is added in fp32 in the epilogue).
@@ -317,13 +419,51 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
 
+    constexpr bool PERSIST = BF && HM_PERSIST && MODE != HM_MODE_HIST;
+    static_assert(!PERSIST || (32 * TM * WPB) % (32 * TN) == 0, "row blocks must start on a tile boundary");
+    constexpr int TPR = (32 * TM * WPB) / (32 * TN) > 0 ? (32 * TM * WPB) / (32 * TN) : 1;   // diagonal advance per row block, in tiles
+    // tiles of the sequence in front of relative row block q
+    auto seq_before = [&](long long q) { return q * p.nct - (long long)TPR * ((long long)p.rb_first * q + q * (q - 1) / 2); };
+    long long pos = 0, pos_end = 0;
+    if (PERSIST) {
+        pos = p.p_total * (long long)blockIdx.x / (long long)gridDim.x;
+        pos_end = p.p_total * ((long long)blockIdx.x + 1) / (long long)gridDim.x;
+        if (pos >= pos_end) return;
+    }
+    uint32_t sure_total = 0;         // per-lane partial of the sure count
+    unsigned long long gk = ~0ull;   // last value read of the running argmin key
+    unsigned long long gk_raw = ~0ull;   // destination of the asynchronous key load
+    bool gk_pending = false;
+    const uint32_t lds_base = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)smem);
+
+    uint32_t* lhist = nullptr;
+    if (MODE == HM_MODE_HIST) {
+        lhist = reinterpret_cast<uint32_t*>(smem + NBUF * TILE_LDS);
+        for (int t = threadIdx.x; t < HM_HIST_BINS; t += NTHREADS) lhist[t] = 0;
+    }
+
+    do {   // one pass per (row block, run of column tiles); a single pass unless PERSIST
     int rb, ct0, ct1;
+    if (PERSIST) {
+        int lo = 0, hi = p.p_nrb - 1;                       // largest q with seq_before(q) <= pos
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seq_before(mid) <= pos) lo = mid; else hi = mid - 1;
+        }
+        const long long q0 = seq_before(lo), q1 = seq_before(lo + 1);
+        const long long run_end = pos_end < q1 ? pos_end : q1;
+        rb = p.rb_first + lo;
+        ct0 = rb * TPR + (int)(pos - q0);
+        ct1 = ct0 + (int)(run_end - pos);
+        pos = run_end;
+    }
     auto slot_to_chunk = [&](int slot) {
         if (!p.swizzle || HM_SWIZZLE_IDENTITY) return slot;
         const int q = slot & 15;
         return (slot & ~15) | (q < 8 ? q : 23 - q);
     };
-    if (p.skip_empty) {
+    if (PERSIST) {
+    } else if (p.skip_empty) {
         // triangular item numbering: local row r of a phase owns chunks floor(r / m) .. chunks - 1
         // (m = rows per chunk step of the diagonal), so no block is launched left of the diagonal
         const bool ph_a = (int)blockIdx.x < p.n_items_a;
@@ -359,23 +499,13 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
 
     // The MFMA result u_f (plain fmaf chain) and the canonical u_c (torch reduction order) are two
     // roundings of the same exact form; |u_f - u_c| <= delta (gamma_n bound on both, |terms| <= rmax2).
-    const float rmax2 = hm::bitsf(p.rmax2_bits[0]);
-    float delta = ((float)((BF ? 16 * NG : RS) + 8) * 1.1920929e-07f) * rmax2 * 1.0001f;
-    // bf16 operands: each spatial product carries <= 2 * 2^-9 (+ 2^-18) relative error, so the sum is
-    // off by <= 2^-8 (1 + 2^-9) * ||x_s|| ||y_s|| <= 0.00392 * (largest squared spatial norm)
-    // and the hi+lo split of the time coordinate leaves <= 2^-15 * x0*y0 (x0^2 <= rmax2)
-    if (BF) delta += 0.00392f * hm::bitsf(p.rmax2_bits[1]) + 3.1e-5f * rmax2;
+    const float delta = hm_scan_delta(BF != 0, BF ? 16 * NG : RS, p.rmax2_bits);
     const float pre_f = p.u_hi + delta;              // candidate prefilter on u_f
     const float lo_f = p.u_lo - delta;               // u_f below this: canonical d < thr for sure
     const float zmax_f = 1.0f - delta;               // u_f at or below this: canonical u <= 1, d == 0
     const bool cut_all = (p.cut_bits == 0xffffffffu);
     const float cut_f = cut_all ? p.u_hi : hm::bitsf(p.cut_bits) + delta;
 
-    uint32_t* lhist = nullptr;
-    if (MODE == HM_MODE_HIST) {
-        lhist = reinterpret_cast<uint32_t*>(smem + NBUF * TILE_LDS);
-        for (int t = threadIdx.x; t < HM_HIST_BINS; t += NTHREADS) lhist[t] = 0;
-    }
 
     // ---- stationary A fragments: lane (r, h) keeps its operands of every k-step in registers ----
     float2 a[BF ? 1 : TM][BF ? 1 : NP];            // fp32 form: 2 operands (two k-steps) per group
@@ -409,8 +539,8 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
     // Issued through inline asm so that hipcc does not drain it (vmcnt(0)) before the LDS reads of
     // the tile being computed; the matching wait is the explicit vmcnt(0) in front of the barrier
     // that ends each iteration (cdna_hip_programming.md section 5.7, LDS-DMA recipe).
-    const uint32_t lds_base = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)smem);
     auto dma_piece = [&](int ct, int buf, int q) {          // q: wave-uniform piece index in [0, PPW * WPB)
+        if (HM_DIAG_NO_DMA && BF) return;
         // pieces past NPIECE (ring-slot padding) read the first KiB of the next tile: in bounds, unused
         const char* src = (BF ? reinterpret_cast<const char*>(p.img16) : reinterpret_cast<const char*>(p.img)) +
                           (int64_t)ct * TILE_BYTES + lane * 16 + q * 1024;
@@ -422,8 +552,16 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                      : "memory");
     };
     auto dma_tile = [&](int ct, int buf) {
+        if constexpr (BF && HM_DMA_GROUPED) {
+            // bf16 form: wave w moves the PPW consecutive pieces [w * PPW, (w + 1) * PPW), four per statement
+            if (HM_DIAG_NO_DMA) return;
+            const char* src = reinterpret_cast<const char*>(p.img16) + (int64_t)(HM_DIAG_SAME_TILES ? (ct & 7) : ct) * TILE_BYTES + lane * 16 + wave * (PPW * 1024);
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * (uint32_t)TILE_LDS + (uint32_t)wave * (PPW * 1024u));
+            hm_dma_run<PPW>(src, dst);
+        } else {
 #pragma unroll
-        for (int t = 0; t < PPW; ++t) dma_piece(ct, buf, t * WPB + wave);
+            for (int t = 0; t < PPW; ++t) dma_piece(ct, buf, t * WPB + wave);
+        }
     };
     // every wave issues exactly PPW pieces per tile, so "tile x has landed" is a counted wait:
     // all but the (tiles issued after x) * PPW youngest vector-memory operations are complete
@@ -450,15 +588,21 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
     auto tile_at = [&](int t) { int q = t + rot; if (q >= ntile) q -= ntile; return ct0 + q * ct_step; };
 
     // ring prologue: tiles 0 .. DIST-1 in flight, tile 0 landed
+    constexpr bool ALWAYS = BF && HM_DMA_GROUPED;    // the ring always holds DIST tiles in flight (a repeat of the last
+                                                      // tile goes into the free slot when the chunk runs out): no branches
 #pragma unroll
     for (int q = 0; q < DIST; ++q)
-        if (q < ntile) dma_tile(tile_at(q), q);
-    wait_tiles_in_flight((ntile < DIST ? ntile : DIST) - 1);
+        if (ALWAYS || q < ntile) dma_tile(tile_at(q < ntile ? q : ntile - 1), q);
+    wait_tiles_in_flight(ALWAYS ? DIST - 1 : (ntile < DIST ? ntile : DIST) - 1);
+#if HM_SETTLE_PROLOGUE
+    // The compiler waits for its own loads (the A fragments above) lazily, at their first use INSIDE the
+    // loop -- with vmcnt(N) instructions that also wait for the ring's LDS-DMA (which it cannot see) on
+    // every iteration.  A wait it can see, here, settles them before the loop is entered.
+    if (DIST == 1) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+#endif
     __syncthreads();
 
-    uint32_t sure_total = 0;         // per-lane partial of the sure count
     int buf = 0;                     // ring slot of tile t
-    unsigned long long gk = ~0ull;   // last value read of the running argmin key
 
 
     for (int t = 0; t < ntile; ++t) {
@@ -471,7 +615,17 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
         const int j0 = ct * COLS;
         const bool compute = wave_active && (j0 + COLS - 1 > i0w);
 
-        if (!HM_DMA_INTERLEAVE || !compute || (!BF && NP - 1 < PPW)) {
+        if (ALWAYS) {
+            // running best key, re-read every 8th tile by a load the compiler does not see (it would wait for
+            // it with vmcnt(0) in front of the MFMA loop and so serialise the ring): the value is picked up
+            // behind this iteration's own counted wait.  Issued ahead of the tile's DMA, so that wait covers it.
+            static_assert(!(BF && HM_DMA_GROUPED) || DIST <= 2, "the key load rides on the counted wait of a ring of <= 3 slots");
+            if (MODE == HM_MODE_ARGMIN && (t & 7) == 0) {
+                asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(gk_raw) : "v"(&p.ctr64[1]) : "memory");
+                gk_pending = true;
+            }
+            dma_tile(ct_next, buf_next);
+        } else if (!HM_DMA_INTERLEAVE || !compute || (!BF && NP - 1 < PPW)) {
             if (has_next) dma_tile(ct_next, buf_next);
         } else if (BF && NP < PPW) {
             // more pieces than k-steps: the first PPW - NP go out ahead of the MFMA loop
@@ -485,7 +639,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
             // running best key of the argmin search, refreshed every 8th tile only: hipcc waits for
             // this vector load with vmcnt(0), which also drains the LDS-DMA ring.  A stale key only
             // emits a few more entries.
-            if (MODE == HM_MODE_ARGMIN && (t & 7) == 0)
+            if (MODE == HM_MODE_ARGMIN && !ALWAYS && (t & 7) == 0)
                 gk = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
@@ -504,13 +658,17 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                 for (int g = 0; g < NP; ++g) {
                     if (g + 1 < NP) {
 #pragma unroll
-                        for (int tn = 0; tn < TN; ++tn) bn[tn] = *reinterpret_cast<const uint4*>(bt + 32 * tn * RB16 + 32 * (g + 1));
+                        for (int tn = 0; tn < TN; ++tn)
+                            if (HM_DIAG_NO_LDS) { bn[tn] = bc[tn]; bn[tn].x += g; }
+                            else bn[tn] = *reinterpret_cast<const uint4*>(bt + 32 * tn * RB16 + 32 * (g + 1));
                     }
-                    if (HM_DMA_INTERLEAVE && g < PPW && g < NP && has_next) dma_piece(ct_next, buf_next, g * WPB + wave);
+                    if (!ALWAYS && HM_DMA_INTERLEAVE && g < PPW && g < NP && has_next) dma_piece(ct_next, buf_next, g * WPB + wave);
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                         for (int tn = 0; tn < TN; ++tn)
+                            if (HM_DIAG_NO_MFMA) acc[tm][tn][g] += __builtin_bit_cast(float, bc[tn].x ^ a16[tm][g].y);
+                            else
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
                                                                                  __builtin_bit_cast(bf16x8, bc[tn]), acc[tm][tn], 0, 0, 0);
 #pragma unroll
@@ -587,98 +745,121 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                 }
             }
 
-            if (__ballot(ext_u < bound_f) != 0ull) {
-                const bool full = rows_full && (j0 > i0w + WAVE_ROWS - 1) && (j0 + COLS - 1 < p.n);
-                // -------- slow path: per-element predicates, evaluated twice (count, then write).
-                // The second evaluation runs on laundered copies of the bounds so that the compiler
-                // does not keep 64 predicates alive across the wave scan (that spills).
-                uint32_t n_emit = 0, n_sure = 0;
-                unsigned long long wkey = ~0ull;
-                float bnd = bound_f;
-                float cutv = cut_f;
-                uint32_t slot = 0;
-                auto visit = [&](const float w, const int tm, const int tn, const int e, const bool write) {
-                    const float u = SIGN ? -w : w;
-                    const int i = i0w + 32 * tm + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const int j = j0 + 32 * tn + r;
-                    bool pass = u < bnd;
-                    if (!full) pass = pass && (i < j) && (j < p.n) && (i >= p.row_begin) && (i < p.row_end);
-                    if (!pass) return;
-                    const float up = u < 1.0f ? 1.0f : u;
-                    const uint32_t ub = hm::fbits(up);
-                    if (MODE == HM_MODE_HIST) {
-                        if (ub >= p.hist_lo) {
-                            uint32_t bin = (ub - p.hist_lo) >> p.hist_shift;
-                            if (bin > HM_HIST_BINS - 1) bin = HM_HIST_BINS - 1;
-                            atomicAdd(&lhist[bin], 1u);
-                        }
-                        return;
-                    }
-                    bool emit;
-                    uint32_t flag = 0;
-                    const bool zero = (u <= zmax_f) && (p.thr_pos != 0);     // certainly d == 0 < thr
-                    if (MODE == HM_MODE_TOPK) {
-                        const bool sure = zero || (up < lo_f);
-                        if (sure && !write) ++n_sure;
-                        flag = sure ? 1u : 0u;
-                        // zero-distance ties order by (i, j): a tie flood is cut by rows (tie_imax)
-                        emit = zero ? (i <= p.tie_imax) : (!sure || cut_all || up <= cutv);
-                    } else {
-                        const uint32_t ubz = zero ? 0x3f7fffffu : ub;
-                        const uint32_t low = ((uint32_t)i << 15) | ((uint32_t)j >> 2);
-                        emit = !(zero && best_bits == 0x3f7fffffu) || (low <= best_low);
-                        if (emit && !write) {
-                            const unsigned long long k = ((unsigned long long)ubz << 32) | low;
-                            wkey = k < wkey ? k : wkey;
-                        }
-                    }
-                    if (!emit) return;
-                    if (!write) { ++n_emit; return; }
-                    if (slot < p.ent_cap) p.ent[slot] = make_uint4(ub, (uint32_t)i, (uint32_t)j, flag);
-                    ++slot;
-                };
+            float diag_sum = 0.0f;
+            if (HM_DIAG_NO_EPI && BF) {
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn)
+                    for (int tn = 0; tn < TN; ++tn) diag_sum += acc[tm][tn][0];
+            }
+            if (HM_DIAG_NO_EPI && BF ? (diag_sum == 12345.0f) : __ballot(ext_u < bound_f) != 0ull) {
+                const bool full = rows_full && (j0 > i0w + WAVE_ROWS - 1) && (j0 + COLS - 1 < p.n);
+                // -------- slow path, one 32x32 MFMA tile at a time (a rolled loop: the hot loop must not
+                // inherit its register pressure).  Per-element predicates are evaluated twice (count, then
+                // write); the second evaluation runs on laundered copies of the bounds so that the compiler
+                // does not keep the predicates alive across the wave scan.
+                unsigned long long wkey = ~0ull;
+                bool wrote = false;
+#pragma unroll 1
+                for (int sub = 0; sub < (HM_DIAG_NO_SLOW ? 0 : TM * TN); ++sub) {
+                    f32x16 w = acc[0][0];
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) visit(acc[tm][tn][e], tm, tn, e, false);
-
-                if (MODE != HM_MODE_HIST) {
+                    for (int q = 1; q < TM * TN; ++q)
+                        if (sub == q) w = acc[q / TN][q % TN];
+                    const int tm = sub / TN, tn = sub - tm * TN;
+                    if (TM * TN > 1) {
+                        float e1 = w[0];
+#pragma unroll
+                        for (int e = 1; e < 16; ++e) e1 = SIGN ? __builtin_fmaxf(e1, w[e]) : __builtin_fminf(e1, w[e]);
+                        if (__ballot((SIGN ? -e1 : e1) < bound_f) == 0ull) continue;
+                    }
+                    uint32_t n_emit = 0, n_sure = 0;
+                    float bnd = bound_f;
+                    float cutv = cut_f;
+                    uint32_t slot = 0;
+                    const int ib = i0w + 32 * tm + 4 * h;
+                    const int j = j0 + 32 * tn + r;
+                    auto visit = [&](const float wv, const int e, const bool write) {
+                        const float u = SIGN ? -wv : wv;
+                        const int i = ib + (e & 3) + 8 * (e >> 2);
+                        bool pass = u < bnd;
+                        if (!full) pass = pass && (i < j) && (j < p.n) && (i >= p.row_begin) && (i < p.row_end);
+                        if (!pass) return;
+                        const float up = u < 1.0f ? 1.0f : u;
+                        const uint32_t ub = hm::fbits(up);
+                        if (MODE == HM_MODE_HIST) {
+                            if (ub >= p.hist_lo) {
+                                uint32_t bin = (ub - p.hist_lo) >> p.hist_shift;
+                                if (bin > HM_HIST_BINS - 1) bin = HM_HIST_BINS - 1;
+                                atomicAdd(&lhist[bin], 1u);
+                            }
+                            return;
+                        }
+                        bool emit;
+                        uint32_t flag = 0;
+                        const bool zero = (u <= zmax_f) && (p.thr_pos != 0);     // certainly d == 0 < thr
+                        if (MODE == HM_MODE_TOPK) {
+                            const bool sure = zero || (up < lo_f);
+                            if (sure && !write) ++n_sure;
+                            flag = sure ? 1u : 0u;
+                            // zero-distance ties order by (i, j): a tie flood is cut by rows (tie_imax)
+                            emit = zero ? (i <= p.tie_imax) : (!sure || cut_all || up <= cutv);
+                        } else {
+                            const uint32_t ubz = zero ? 0x3f7fffffu : ub;
+                            const uint32_t low = ((uint32_t)i << 15) | ((uint32_t)j >> 2);
+                            emit = !(zero && best_bits == 0x3f7fffffu) || (low <= best_low);
+                            if (emit && !write) {
+                                const unsigned long long k = ((unsigned long long)ubz << 32) | low;
+                                wkey = k < wkey ? k : wkey;
+                            }
+                        }
+                        if (!emit) return;
+                        if (!write) { ++n_emit; return; }
+                        if (slot < p.ent_cap) p.ent[slot] = make_uint4(ub, (uint32_t)i, (uint32_t)j, flag);
+                        ++slot;
+                    };
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) visit(w[e], e, false);
+                    if (MODE == HM_MODE_HIST) continue;
                     sure_total += n_sure;
                     const uint32_t incl = hm_wave_incl_scan(n_emit, lane);
                     const uint32_t total = __shfl(incl, 63, 64);
-                    if (total != 0) {
-                        uint32_t base = 0;
-                        if (lane == 63) base = atomicAdd(&p.ctr[0], total);
-                        base = __shfl(base, 63, 64);
-                        slot = base + incl - n_emit;
-                        asm volatile("" : "+v"(bnd), "+v"(cutv));      // opaque: no CSE with the count pass
+                    if (total == 0) continue;
+                    uint32_t base = 0;
+                    if (lane == 63) base = atomicAdd(&p.ctr[0], total);
+                    base = __shfl(base, 63, 64);
+                    slot = base + incl - n_emit;
+                    asm volatile("" : "+v"(bnd), "+v"(cutv));      // opaque: no CSE with the count pass
 #pragma unroll
-                        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                                for (int e = 0; e < 16; ++e) visit(acc[tm][tn][e], tm, tn, e, true);
-                        if (MODE == HM_MODE_ARGMIN) {
-                            const unsigned long long wk = hm_wave_min_u64(wkey);
-                            if (lane == 0) atomicMin(&p.ctr64[1], wk);
-                            // the slow path has drained the vector-memory queue anyway: refresh the
-                            // running key now (cheap here) so that the next tiles see the tight bound
-                            gk = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (wk < gk) gk = wk;
-                        }
-                    }
+                    for (int e = 0; e < 16; ++e) visit(w[e], e, true);
+                    wrote = true;
+                }
+                if (MODE == HM_MODE_ARGMIN && wrote) {
+                    const unsigned long long wk = hm_wave_min_u64(wkey);
+                    if (lane == 0) atomicMin(&p.ctr64[1], wk);
+                    // the slow path has drained the vector-memory queue anyway: refresh the running key
+                    // now (cheap here) so that the next tiles see the tight bound
+                    gk = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (wk < gk) gk = wk;
                 }
             }
         }
-        {   // tile t+1 has landed (this wave's pieces): tiles t+2 .. min(t+DIST, ntile-1) may stay in flight
+        if (ALWAYS) {
+            // tile t+1 has landed (this wave's pieces) -- and so has the key load, if one was issued
+            if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gk_raw) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gk_raw) : "n"((DIST - 1) * PPW) : "memory");
+            if (MODE == HM_MODE_ARGMIN && gk_pending) {
+                if (gk_raw < gk) gk = gk_raw;               // the key only ever decreases
+                gk_pending = false;
+            }
+        } else {   // tile t+1 has landed (this wave's pieces): tiles t+2 .. min(t+DIST, ntile-1) may stay in flight
             const int last = (t + DIST < ntile - 1) ? t + DIST : ntile - 1;
             wait_tiles_in_flight(last - (t + 1));
         }
-        __syncthreads();                                    // ... and every wave's; all reads of slot `buf` done
+        if (!(HM_DIAG_NO_BARRIER && BF)) __syncthreads();   // ... and every wave's; all reads of slot `buf` done
         if (++buf == NBUF) buf = 0;
     }
+    } while (PERSIST && pos < pos_end);
 
     if (MODE == HM_MODE_TOPK) {
         // one 64-bit atomic per wave for the sure count
@@ -746,16 +927,31 @@ __global__ __launch_bounds__(256) void hm_post_argmin_kernel(const uint4* __rest
     if (threadIdx.x == 0) { parts[blockIdx.x].dbits = b0; parts[blockIdx.x].i = b1; parts[blockIdx.x].j = b2; parts[blockIdx.x].pad = 0; }
 }
 
+// seed == nullptr: no seed update (hm_row_argmin).  Otherwise a final record (found == 1) becomes the next
+// search's seed: key = (bits(u_c + delta), all ones) -- the pair's own prefilter value is <= u_c + delta, and
+// an entry the scan skips on this key has u_f >= u_c + 3 delta, so it cannot order before the pair -- or,
+// for a pair at distance 0 (u_c <= 1), the exact zero-class key with its (i, j) part.
 __global__ __launch_bounds__(HM_ARGMIN_BLOCKS) void hm_post_argmin_final_kernel(const ArgminPart* __restrict__ parts, ArgminRec* out,
-                                                                                const uint32_t* __restrict__ ctr, uint32_t cap)
+                                                                                const uint32_t* __restrict__ ctr, uint32_t cap,
+                                                                                ArgminSeed* seed, const float* __restrict__ img, int RS, int d,
+                                                                                int sign_mode, int bf, int kterms,
+                                                                                const uint32_t* __restrict__ rmax2_bits)
 {
     __shared__ uint32_t s0[HM_ARGMIN_BLOCKS], s1[HM_ARGMIN_BLOCKS], s2[HM_ARGMIN_BLOCKS];
     uint32_t b0 = parts[threadIdx.x].dbits, b1 = parts[threadIdx.x].i, b2 = parts[threadIdx.x].j;
     hm_block_min_key(b0, b1, b2, s0, s1, s2);
     if (threadIdx.x == 0) {
         // found = 2: the emission buffer overflowed, the record is not final (caller reruns bounded)
-        out->found = ctr[0] > cap ? 2u : ((b1 != 0xffffffffu) ? 1u : 0u);
+        const uint32_t found = ctr[0] > cap ? 2u : ((b1 != 0xffffffffu) ? 1u : 0u);
+        out->found = found;
         out->dbits = b0; out->i = b1; out->j = b2;
+        if (seed != nullptr && found == 1u) {
+            const float u = hm_img_u(img, RS, d, b1, b2, sign_mode);
+            unsigned long long key;
+            if (u <= 1.0f) key = (0x3f7fffffull << 32) | (unsigned long long)((b1 << 15) | (b2 >> 2));
+            else key = ((unsigned long long)hm::fbits(u + hm_scan_delta(bf != 0, kterms, rmax2_bits)) << 32) | 0xffffffffull;
+            seed->key = key; seed->i = b1; seed->valid = 1u;
+        }
     }
 }
 
@@ -1096,6 +1292,7 @@ struct HostCtl {                 // pinned host mirror of small device results
 
 struct hm_engine {
     int device = 0;
+    int n_cu = 256;                       // compute units of the device (resident-block count of the persistent scan)
     int64_t max_rows = 0, rows_alloc = 0, n = 0;
     int d1 = 0, d = 0, NG = 0, RS = 0, sign_mode = 0;
     float* img = nullptr;
@@ -1111,6 +1308,7 @@ struct hm_engine {
     uint32_t* d_rmax2 = nullptr;          // float bits: [0] largest squared row norm, [1] largest squared spatial norm
     unsigned long long* d_ctr64 = nullptr; // 2 x u64
     ArgminRec* d_rec = nullptr;
+    ArgminSeed* d_seed = nullptr;         // running-key seed of the next argmin search (device-resident state)
     ArgminPart* d_parts = nullptr;
     uint32_t* d_hist = nullptr;           // HM_DIGIT_BINS
     HostCtl* h = nullptr;                 // pinned
@@ -1207,6 +1405,10 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     e->ent_cap = 1u << 24;
     e->sorted_cap = 1u << 16;
     HM_HIP(hipSetDevice(device));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) e->n_cu = cus;
+    }
     HM_HIP(hipMalloc(&e->img, sizeof(float) * (size_t)e->rows_alloc * e->RS));
     HM_HIP(hipMemset(e->img, 0, sizeof(float) * (size_t)e->rows_alloc * e->RS));
     HM_HIP(hipMalloc(&e->img16, (size_t)e->rows_alloc * e->RB16));
@@ -1218,6 +1420,8 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     HM_HIP(hipMalloc(&e->d_rmax2, sizeof(uint32_t) * 2));
     HM_HIP(hipMemset(e->d_rmax2, 0, sizeof(uint32_t) * 2));
     HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 2));
+    HM_HIP(hipMalloc(&e->d_seed, sizeof(ArgminSeed)));
+    HM_HIP(hipMemset(e->d_seed, 0, sizeof(ArgminSeed)));
     HM_HIP(hipMalloc(&e->d_rec, sizeof(ArgminRec)));
     HM_HIP(hipMalloc(&e->d_parts, sizeof(ArgminPart) * HM_ARGMIN_BLOCKS));
     HM_HIP(hipMalloc(&e->d_hist, sizeof(uint32_t) * HM_DIGIT_BINS));
@@ -1233,7 +1437,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
 {
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
-    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts, e->img16};
+    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts, e->img16, e->d_seed};
     for (void* q : dev_ptrs) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);
     if (e->h_sorted) (void)hipHostFree(e->h_sorted);
@@ -1277,6 +1481,7 @@ extern "C" int hm_set_table(hm_engine* e, const float* X_dev, int64_t ld, int64_
     if (rc) return rc;
     e->n = n_rows;
     e->have_cut = false;
+    HM_HIP(hipMemsetAsync(e->d_seed, 0, sizeof(ArgminSeed), s));      // new table: no seed
     return HM_OK;
 }
 
@@ -1288,7 +1493,10 @@ extern "C" int hm_update_rows(hm_engine* e, const float* X_dev, int64_t ld, int6
     HM_HIP(hipSetDevice(e->device));
     int rc = hm_build_rows(e, X_dev, ld, row_begin, row_end, (hipStream_t)stream);
     if (rc) return rc;
-    if (row_begin < e->n) e->have_cut = false;       // an existing row changed: cut prediction void
+    if (row_begin < e->n) {                          // an existing row changed: cut prediction and argmin seed void
+        e->have_cut = false;
+        HM_HIP(hipMemsetAsync(e->d_seed, 0, sizeof(ArgminSeed), (hipStream_t)stream));
+    }
     if (row_end > e->n) e->n = row_end;
     return HM_OK;
 }
@@ -1369,6 +1577,7 @@ static bool hm_use_bf16(const hm_engine* e)
 
 static hipError_t hm_launch_scan(const hm_engine* e, int mode, const ScanArgs& a, dim3 grid, hipStream_t s)
 {
+    if (a.bf16 && HM_PERSIST && mode != HM_MODE_HIST) grid = dim3((unsigned)a.p_grid, 1, 1);
     if (a.bf16) {
         switch (e->KS) {
             case 1: return hm_launch_scan_ng<1, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
@@ -1482,6 +1691,10 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     }
 #endif
     grid = dim3((unsigned)std::max(1, a.n_items_a + n_items_b), 1, 1);
+    // persistent decomposition (used by the bf16 TOPK / ARGMIN launches, see hm_scan_grid)
+    a.p_nrb = nrb;
+    a.p_total = (long long)nrb * a.nct - (long long)tiles_per_rb * ((long long)a.rb_first * nrb + (long long)nrb * (nrb - 1) / 2);
+    a.p_grid = (int)std::max<long long>(1, std::min<long long>((long long)e->n_cu * HM_PERSIST_BLOCKS_PER_CU, a.p_total / 4));
     return true;
 }
 
@@ -1503,6 +1716,9 @@ static void hm_flush_pending_timing(hm_engine* e)
     e->pending_timing = false;
 }
 
+// arguments of hm_post_argmin_final_kernel that describe the seed update
+#define HM_SEED_ARGS(e, a) (e)->d_seed, (e)->img, (e)->RS, (e)->d, (e)->sign_mode, (a).bf16, ((a).bf16 ? 16 * (e)->KS : (e)->RS), (e)->d_rmax2
+
 extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end, uint32_t* rec_dev,
                                       void* stream)
 {
@@ -1519,7 +1735,8 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
         return HM_OK;
     }
     HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
-    HM_HIP(hipMemsetAsync(e->d_ctr64, 0xff, sizeof(unsigned long long) * 2, s));
+    hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(1), 0, s, e->d_seed, e->d_ctr64, a.row_begin, a.row_end);
+    HM_HIP(hipGetLastError());
     HM_HIP(hipEventRecord(e->ev0, s));
     HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s));
     HM_HIP(hipEventRecord(e->ev1, s));
@@ -1527,7 +1744,7 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
                        e->d, e->sign_mode, sqrtf(c), thr, e->d_parts);
     HM_HIP(hipGetLastError());
     hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts,
-                       reinterpret_cast<ArgminRec*>(rec_dev), e->d_ctr, e->ent_cap);
+                       reinterpret_cast<ArgminRec*>(rec_dev), e->d_ctr, e->ent_cap, HM_SEED_ARGS(e, a));
     HM_HIP(hipGetLastError());
     e->pending_timing = true;
     e->pending_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
@@ -1553,14 +1770,18 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
         HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
         // pass 1 (after an overflow) keeps the final running key of pass 0: every wave then starts
         // with the tight bound and only the band around the minimum is emitted
-        if (pass == 0) HM_HIP(hipMemsetAsync(e->d_ctr64, 0xff, sizeof(unsigned long long) * 2, s));
+        if (pass == 0) {
+            hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(1), 0, s, e->d_seed, e->d_ctr64, a.row_begin, a.row_end);
+            HM_HIP(hipGetLastError());
+        }
         HM_HIP(hipEventRecord(e->ev0, s));
         HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s));
         HM_HIP(hipEventRecord(e->ev1, s));
         hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(HM_ARGMIN_BLOCKS), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img,
                            e->RS, e->d, e->sign_mode, sqrt_c, thr, e->d_parts);
         HM_HIP(hipGetLastError());
-        hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec, e->d_ctr, e->ent_cap);
+        hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec, e->d_ctr, e->ent_cap,
+                           HM_SEED_ARGS(e, a));
         HM_HIP(hipGetLastError());
         HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
         HM_HIP(hipMemcpyAsync(e->h->ctr, e->d_ctr, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, s));
@@ -1876,7 +2097,8 @@ extern "C" int hm_row_argmin(hm_engine* e, int64_t row, int64_t n_partners, floa
     hipLaunchKernelGGL(hm_row_argmin_kernel, dim3(HM_ARGMIN_BLOCKS), dim3(256), 0, s, e->img, e->RS, e->d, e->sign_mode, row,
                        n_partners, sqrtf(c), thr, e->d_parts);
     HM_HIP(hipGetLastError());
-    hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec, e->d_ctr, e->ent_cap);
+    hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec, e->d_ctr, e->ent_cap,
+                       (ArgminSeed*)nullptr, e->img, e->RS, e->d, e->sign_mode, 0, e->RS, e->d_rmax2);
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
     HM_HIP(hipStreamSynchronize(s));
@@ -1923,7 +2145,10 @@ extern "C" int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, floa
     hipLaunchKernelGGL(hm_merge_append_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d, e->NG, i, j, w, c,
                        e->sign_mode, X_dev, ld, new_row, e->d_rmax2, e->img16, e->KS);
     HM_HIP(hipGetLastError());
-    if (new_row < e->n) e->have_cut = false;
+    if (new_row < e->n) {
+        e->have_cut = false;
+        HM_HIP(hipMemsetAsync(e->d_seed, 0, sizeof(ArgminSeed), (hipStream_t)stream));
+    }
     if (new_row + 1 > e->n) e->n = new_row + 1;
     return HM_OK;
 }

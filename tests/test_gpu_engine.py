@@ -173,3 +173,52 @@ def test_banded_decomposition_matches_oracle(oracle, mode):
         assert (a is None) == (oc == 0)
         if a:
             assert (a[1], a[2]) == (int(oi[0]), int(oj[0]))
+
+
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_argmin_seed_follows_table_edits(oracle, mode):
+    """the search seeds its running key with the previous nearest pair (valid while rows are only
+    appended); editing or replacing a row must drop the seed, appends and range searches must not be
+    misled by it"""
+    n, d = 2600, 30
+    X = lorentz_table(n, d, seed=21, scale=0.05).numpy()
+    eng, table = _engine(torch.from_numpy(X), mode, max_rows=n + 64)
+    thr = 0.6 if mode == "lorentz" else 0.1
+
+    def check(live, r0=0, r1=-1):
+        got = eng.argmin(1.0, thr, r0, r1)
+        od, oi, oj, oc = oracle.pairwise_topk(live, live.shape[0], 1.0, thr, MODES[mode], 1, r0, live.shape[0] if r1 < 0 else r1)
+        assert (got is None) == (oc == 0), (r0, r1)
+        if got:
+            assert (got[1], got[2]) == (int(oi[0]), int(oj[0])) and _bits([got[0]])[0] == _bits(od)[0], (r0, r1)
+        return got
+
+    first = check(X)
+    assert check(X) == first                                     # seeded repeat
+    assert first is not None
+    i, j = first[1], first[2]
+    # ranges that do / do not contain the seed's row
+    check(X, i, i + 1)
+    check(X, min(i + 1, n - 2), n)
+    check(X, 0, max(i, 1))
+    # move one end of the nearest pair far away: the old key is no bound any more
+    far = lorentz_table(1, d, seed=99, scale=1.0).numpy()[0]
+    X2 = X.copy()
+    X2[j] = far
+    table[j] = torch.from_numpy(far).cuda()
+    eng.update_rows(table, j, j + 1)
+    second = check(X2)
+    assert mode == "reference" or second != first       # literal mode: every distance is 0, (0, 1) stays first
+    # a whole new table
+    X3 = lorentz_table(n, d, seed=22, scale=0.05).numpy()
+    table[:n] = torch.from_numpy(X3).cuda()
+    eng.set_table(table, n)
+    check(X3)
+    # appends keep the seed: duplicate of a row -> distance 0 must win over the seeded key
+    table[n] = table[17]
+    eng.update_rows(table, n, n + 1)
+    X4 = np.concatenate([X3, X3[17:18]], 0)
+    got = check(X4)
+    if mode == "lorentz":
+        assert got is not None and (got[1], got[2]) == (17, n) and got[0] == 0.0
+    check(X4)

@@ -1,11 +1,11 @@
 """Interleaved A/B timing of pair-scan kernel variants in ONE process (cdna guide rule 24).
 usage: python tools/ab_scan.py build_variants/libhm_a.so build_variants/libhm_b.so ..."""
-import sys, statistics, numpy as np, torch
+import os, sys, statistics, numpy as np, torch
 sys.path.insert(0, ".")
 from hyptokenizer_amd import _lib
 from hyptokenizer_amd.engine import MergeEngine
 from hyptokenizer_amd.synthetic import lorentz_table
-V, d = 50000, 100
+V, d = int(os.environ.get('AB_V', 50000)), int(os.environ.get('AB_D', 100))
 X = lorentz_table(V, d, seed=42, scale=0.05)
 table = torch.zeros((V + 64, d + 1), device="cuda"); table[:V] = X.cuda()
 engines = {}
