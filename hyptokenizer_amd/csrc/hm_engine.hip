@@ -588,6 +588,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
     auto tile_at = [&](int t) { int q = t + rot; if (q >= ntile) q -= ntile; return ct0 + q * ct_step; };
 
     // ring prologue: tiles 0 .. DIST-1 in flight, tile 0 landed
+    constexpr bool ASYNC_KEY = (BF && HM_DMA_GROUPED) || DIST == 1;   // the running argmin key is re-read behind the ring's own wait
     constexpr bool ALWAYS = BF && HM_DMA_GROUPED;    // the ring always holds DIST tiles in flight (a repeat of the last
                                                       // tile goes into the free slot when the chunk runs out): no branches
 #pragma unroll
@@ -615,15 +616,15 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
         const int j0 = ct * COLS;
         const bool compute = wave_active && (j0 + COLS - 1 > i0w);
 
+        // running best key, re-read every 8th tile by a load the compiler does not see (it would wait for it
+        // with vmcnt(0) inside the MFMA loop and so drain the ring): the value is picked up behind this
+        // iteration's own counted wait.  Issued ahead of the tile's DMA, so that wait covers it.
+        static_assert(!ALWAYS || DIST <= 2, "the key load rides on the counted wait of a ring of <= 3 slots");
+        if (ASYNC_KEY && MODE == HM_MODE_ARGMIN && (t & 7) == 0) {
+            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(gk_raw) : "v"(&p.ctr64[1]) : "memory");
+            gk_pending = true;
+        }
         if (ALWAYS) {
-            // running best key, re-read every 8th tile by a load the compiler does not see (it would wait for
-            // it with vmcnt(0) in front of the MFMA loop and so serialise the ring): the value is picked up
-            // behind this iteration's own counted wait.  Issued ahead of the tile's DMA, so that wait covers it.
-            static_assert(!(BF && HM_DMA_GROUPED) || DIST <= 2, "the key load rides on the counted wait of a ring of <= 3 slots");
-            if (MODE == HM_MODE_ARGMIN && (t & 7) == 0) {
-                asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(gk_raw) : "v"(&p.ctr64[1]) : "memory");
-                gk_pending = true;
-            }
             dma_tile(ct_next, buf_next);
         } else if (!HM_DMA_INTERLEAVE || !compute || (!BF && NP - 1 < PPW)) {
             if (has_next) dma_tile(ct_next, buf_next);
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
             // running best key of the argmin search, refreshed every 8th tile only: hipcc waits for
             // this vector load with vmcnt(0), which also drains the LDS-DMA ring.  A stale key only
             // emits a few more entries.
-            if (MODE == HM_MODE_ARGMIN && !ALWAYS && (t & 7) == 0)
+            if (MODE == HM_MODE_ARGMIN && !ASYNC_KEY && (t & 7) == 0)
                 gk = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
@@ -848,13 +849,14 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
             // tile t+1 has landed (this wave's pieces) -- and so has the key load, if one was issued
             if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gk_raw) : : "memory");
             else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gk_raw) : "n"((DIST - 1) * PPW) : "memory");
-            if (MODE == HM_MODE_ARGMIN && gk_pending) {
-                if (gk_raw < gk) gk = gk_raw;               // the key only ever decreases
-                gk_pending = false;
-            }
         } else {   // tile t+1 has landed (this wave's pieces): tiles t+2 .. min(t+DIST, ntile-1) may stay in flight
             const int last = (t + DIST < ntile - 1) ? t + DIST : ntile - 1;
             wait_tiles_in_flight(last - (t + 1));
+            if (ASYNC_KEY) asm volatile("" : "+v"(gk_raw) : : "memory");   // DIST == 1: that wait was vmcnt(0)
+        }
+        if (ASYNC_KEY && MODE == HM_MODE_ARGMIN && gk_pending) {
+            if (gk_raw < gk) gk = gk_raw;                   // the key only ever decreases
+            gk_pending = false;
         }
         if (!(HM_DIAG_NO_BARRIER && BF)) __syncthreads();   // ... and every wave's; all reads of slot `buf` done
         if (++buf == NBUF) buf = 0;
