@@ -54,7 +54,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_CHUNK_TILES_BF16 96     // bf16 form: 64-column tiles, ~5x shorter per column than the fp32 form
 #endif
 #ifndef HM_TAIL_FRACTION
-#define HM_TAIL_FRACTION 0.15      // share of the work issued last in quarter-size chunks
+#define HM_TAIL_FRACTION 0.20      // share of the work issued last in quarter-size chunks
 #endif
 #ifndef HM_SKIP_EMPTY
 #define HM_SKIP_EMPTY 0            // triangular item numbering (no block left of the diagonal): no gain measured
@@ -348,11 +348,16 @@ __device__ __forceinline__ float hm_scan_delta(bool bf, int kterms, const uint32
 // pair).  `valid` is cleared whenever an existing row changes.
 struct ArgminSeed { unsigned long long key; uint32_t i, valid; };
 
-__global__ void hm_seed_init_kernel(const ArgminSeed* __restrict__ seed, unsigned long long* __restrict__ ctr64, int row_begin, int row_end)
+// also clears the scan's counters (one launch instead of a memset + a launch)
+__global__ void hm_seed_init_kernel(const ArgminSeed* __restrict__ seed, unsigned long long* __restrict__ ctr64, uint32_t* __restrict__ ctr,
+                                    int row_begin, int row_end)
 {
-    const bool use = seed->valid != 0u && (int)seed->i >= row_begin && (int)seed->i < row_end;
-    ctr64[0] = ~0ull;
-    ctr64[1] = use ? seed->key : ~0ull;
+    if (threadIdx.x < 8) ctr[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) {
+        const bool use = seed->valid != 0u && (int)seed->i >= row_begin && (int)seed->i < row_end;
+        ctr64[0] = ~0ull;
+        ctr64[1] = use ? seed->key : ~0ull;
+    }
 }
 
 // CNT (1..4) consecutive 1 KiB LDS-DMA pieces in one statement: one M0 write; the immediate offset of
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(HM_ARGMIN_BLOCKS) void hm_post_argmin_final_kernel(
                                                                                 const uint32_t* __restrict__ ctr, uint32_t cap,
                                                                                 ArgminSeed* seed, const float* __restrict__ img, int RS, int d,
                                                                                 int sign_mode, int bf, int kterms,
-                                                                                const uint32_t* __restrict__ rmax2_bits)
+                                                                                const uint32_t* __restrict__ rmax2_bits, uint32_t* emitted_out)
 {
     __shared__ uint32_t s0[HM_ARGMIN_BLOCKS], s1[HM_ARGMIN_BLOCKS], s2[HM_ARGMIN_BLOCKS];
     uint32_t b0 = parts[threadIdx.x].dbits, b1 = parts[threadIdx.x].i, b2 = parts[threadIdx.x].j;
@@ -947,6 +952,7 @@ __global__ __launch_bounds__(HM_ARGMIN_BLOCKS) void hm_post_argmin_final_kernel(
         const uint32_t found = ctr[0] > cap ? 2u : ((b1 != 0xffffffffu) ? 1u : 0u);
         out->found = found;
         out->dbits = b0; out->i = b1; out->j = b2;
+        if (emitted_out != nullptr) *emitted_out = ctr[0];      // rides back to the host with the record (one copy)
         if (seed != nullptr && found == 1u) {
             const float u = hm_img_u(img, RS, d, b1, b2, sign_mode);
             unsigned long long key;
@@ -1289,12 +1295,16 @@ struct HostCtl {                 // pinned host mirror of small device results
     uint32_t ctr[8];             // [0] emitted [1] valid [2] valid & !sure [3] compacted [4] margin violations
     unsigned long long ctr64[2]; // [0] sure count [1] argmin key
     ArgminRec rec;
+    ArgminRec rec2[2];           // [0] record, [1].found = emitted count (argmin: one device-to-host copy)
     uint32_t hist[HM_DIGIT_BINS];
 };
 
 struct hm_engine {
     int device = 0;
     int n_cu = 256;                       // compute units of the device (resident-block count of the persistent scan)
+    // work-decomposition knobs (defaults from the macros; HM_TUNE_* environment overrides are a tuning aid)
+    int chunk_f32 = HM_CHUNK_TILES, chunk_bf16 = HM_CHUNK_TILES_BF16, tail_div = 4;
+    double tail_fraction = HM_TAIL_FRACTION;
     int64_t max_rows = 0, rows_alloc = 0, n = 0;
     int d1 = 0, d = 0, NG = 0, RS = 0, sign_mode = 0;
     float* img = nullptr;
@@ -1404,6 +1414,9 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
         const char* pe = getenv("HM_SCAN_PRECISION");          // "f32" | "bf16" | unset = auto
         e->precision = (pe && !strcmp(pe, "f32")) ? 1 : (pe && !strcmp(pe, "bf16")) ? 2 : 0;
     }
+    if (const char* t = getenv("HM_TUNE_CHUNK")) { const int v = atoi(t); if (v >= 4 && v <= 4096) e->chunk_f32 = e->chunk_bf16 = v; }
+    if (const char* t = getenv("HM_TUNE_TAIL")) { const double v = atof(t); if (v >= 0.0 && v <= 0.9) e->tail_fraction = v; }
+    if (const char* t = getenv("HM_TUNE_TAIL_DIV")) { const int v = atoi(t); if (v >= 1 && v <= 16) e->tail_div = v; }
     e->ent_cap = 1u << 24;
     e->sorted_cap = 1u << 16;
     HM_HIP(hipSetDevice(device));
@@ -1424,7 +1437,7 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 2));
     HM_HIP(hipMalloc(&e->d_seed, sizeof(ArgminSeed)));
     HM_HIP(hipMemset(e->d_seed, 0, sizeof(ArgminSeed)));
-    HM_HIP(hipMalloc(&e->d_rec, sizeof(ArgminRec)));
+    HM_HIP(hipMalloc(&e->d_rec, 2 * sizeof(ArgminRec)));
     HM_HIP(hipMalloc(&e->d_parts, sizeof(ArgminPart) * HM_ARGMIN_BLOCKS));
     HM_HIP(hipMalloc(&e->d_hist, sizeof(uint32_t) * HM_DIGIT_BINS));
     HM_HIP(hipHostMalloc(&e->h, sizeof(HostCtl), hipHostMallocDefault));
@@ -1642,7 +1655,7 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     const int nrb = rb_last - a.rb_first + 1;
     const int tiles_per_rb = block_rows / cols;                              // diagonal advance per row block (>= 1)
     // column tiles per block: amortise the stationary-row load, but keep enough blocks in flight
-    int ch = a.bf16 ? HM_CHUNK_TILES_BF16 : HM_CHUNK_TILES;
+    int ch = a.bf16 ? e->chunk_bf16 : e->chunk_f32;
     while (ch > 4 && (int64_t)nrb * ((a.nct + ch - 1) / ch) < 1024) ch >>= 1;
     // phase B = the last ~HM_TAIL_FRACTION of the work (row blocks near the bottom of the triangle),
     // cut into chunks a quarter the size
@@ -1654,9 +1667,9 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
         for (int rb = a.rb_first; rb <= rb_last; ++rb) total += (double)std::max(0, a.nct - rb * tiles_per_rb);
         for (int rb = rb_last; rb >= a.rb_first; --rb) {
             acc += (double)std::max(0, a.nct - rb * tiles_per_rb);
-            if (acc >= HM_TAIL_FRACTION * total) { rb_split = rb; break; }
+            if (acc >= e->tail_fraction * total) { rb_split = rb; break; }
         }
-        ch_b = ch / 4;
+        ch_b = std::max(1, ch / e->tail_div);
     }
     a.ch_a = ch;
     a.chunks_a = std::max(1, (a.nct - a.ctmin_a + ch - 1) / ch);
@@ -1736,8 +1749,7 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
         HM_HIP(hipMemsetAsync(rec_dev, 0, sizeof(ArgminRec), s));        // found = 0
         return HM_OK;
     }
-    HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
-    hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(1), 0, s, e->d_seed, e->d_ctr64, a.row_begin, a.row_end);
+    hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, e->d_ctr64, e->d_ctr, a.row_begin, a.row_end);
     HM_HIP(hipGetLastError());
     HM_HIP(hipEventRecord(e->ev0, s));
     HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s));
@@ -1746,7 +1758,7 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
                        e->d, e->sign_mode, sqrtf(c), thr, e->d_parts);
     HM_HIP(hipGetLastError());
     hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts,
-                       reinterpret_cast<ArgminRec*>(rec_dev), e->d_ctr, e->ent_cap, HM_SEED_ARGS(e, a));
+                       reinterpret_cast<ArgminRec*>(rec_dev), e->d_ctr, e->ent_cap, HM_SEED_ARGS(e, a), (uint32_t*)nullptr);
     HM_HIP(hipGetLastError());
     e->pending_timing = true;
     e->pending_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
@@ -1769,12 +1781,13 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
     if (b.none || e->n < 2 || !hm_prepare_scan(e, b, row_begin, row_end, a, grid)) return HM_OK;
     const float sqrt_c = sqrtf(c);
     for (int pass = 0; pass < 2; ++pass) {
-        HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
         // pass 1 (after an overflow) keeps the final running key of pass 0: every wave then starts
         // with the tight bound and only the band around the minimum is emitted
         if (pass == 0) {
-            hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(1), 0, s, e->d_seed, e->d_ctr64, a.row_begin, a.row_end);
+            hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, e->d_ctr64, e->d_ctr, a.row_begin, a.row_end);
             HM_HIP(hipGetLastError());
+        } else {
+            HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
         }
         HM_HIP(hipEventRecord(e->ev0, s));
         HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s));
@@ -1783,12 +1796,13 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
                            e->RS, e->d, e->sign_mode, sqrt_c, thr, e->d_parts);
         HM_HIP(hipGetLastError());
         hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec, e->d_ctr, e->ent_cap,
-                           HM_SEED_ARGS(e, a));
+                           HM_SEED_ARGS(e, a), reinterpret_cast<uint32_t*>(e->d_rec + 1));
         HM_HIP(hipGetLastError());
-        HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
-        HM_HIP(hipMemcpyAsync(e->h->ctr, e->d_ctr, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, s));
-        HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_ctr64, sizeof(unsigned long long) * 2, hipMemcpyDeviceToHost, s));
+        // record + emitted count (the slot behind the record) in one copy
+        HM_HIP(hipMemcpyAsync(e->h->rec2, e->d_rec, 2 * sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
         HM_HIP(hipStreamSynchronize(s));
+        e->h->rec = e->h->rec2[0];
+        e->h->ctr[0] = e->h->rec2[1].found;
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e->ev0, e->ev1);
         e->last_scan_ms += ms;
@@ -2100,7 +2114,7 @@ extern "C" int hm_row_argmin(hm_engine* e, int64_t row, int64_t n_partners, floa
                        n_partners, sqrtf(c), thr, e->d_parts);
     HM_HIP(hipGetLastError());
     hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec, e->d_ctr, e->ent_cap,
-                       (ArgminSeed*)nullptr, e->img, e->RS, e->d, e->sign_mode, 0, e->RS, e->d_rmax2);
+                       (ArgminSeed*)nullptr, e->img, e->RS, e->d, e->sign_mode, 0, e->RS, e->d_rmax2, (uint32_t*)nullptr);
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
     HM_HIP(hipStreamSynchronize(s));
