@@ -99,12 +99,30 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef HM_DIAG_NO_SLOW
 #define HM_DIAG_NO_SLOW 0
 #endif
+#ifndef HM_DIAG_NEVER_SLOW
+#define HM_DIAG_NEVER_SLOW 0
+#endif
+#ifndef HM_DIAG_TIMES
+#define HM_DIAG_TIMES 0            // per-block {ticks, slow-path entries, passes, tiles} into the hist buffer (hm_debug_read_hist)
+#endif
 #ifndef HM_DIAG_NO_MFMA
 #define HM_DIAG_NO_MFMA 0
+#endif
+#ifndef HM_EVENT_FLAGS
+#define HM_EVENT_FLAGS hipEventDisableSystemFence
 #endif
 #ifndef HM_PERSIST
 #define HM_PERSIST 0               // experiment (off): bf16 form, one resident block per slot walks an equal share of the
                                    // tile sequence -- no launch tail, but measured 50 % slower than the chunked grid
+#endif
+#ifndef HM_DYN_K1
+#define HM_DYN_K1 32
+#endif
+#ifndef HM_DYN_K2
+#define HM_DYN_K2 8
+#endif
+#ifndef HM_DYN_SPLIT
+#define HM_DYN_SPLIT 0.8
 #endif
 #ifndef HM_PERSIST_BLOCKS_PER_CU
 #define HM_PERSIST_BLOCKS_PER_CU 2
@@ -170,6 +188,10 @@ struct ScanArgs {
     // its stationary rows whenever the share crosses into the next row block.
     long long p_total;
     int p_nrb, p_grid;
+    // HM_PERSIST == 2: the sequence is cut into chunks -- p_c1 chunks of p_k1 tiles, then chunks of p_k2 tiles --
+    // which the resident blocks take from an atomic counter (ctr[5]; block b starts with chunk b): blocks
+    // that run faster (the older resident block of a CU wins the arbitration) simply take more of them.
+    int p_k1, p_k2, p_c1;
     float u_hi;             // candidate prefilter: u < u_hi
     float u_lo;             // surely-below-threshold bound: u' < u_lo
     uint32_t cut_bits;      // emit when bits(u') <= cut_bits (or not sure)
@@ -429,8 +451,18 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
     constexpr int TPR = (32 * TM * WPB) / (32 * TN) > 0 ? (32 * TM * WPB) / (32 * TN) : 1;   // diagonal advance per row block, in tiles
     // tiles of the sequence in front of relative row block q
     auto seq_before = [&](long long q) { return q * p.nct - (long long)TPR * ((long long)p.rb_first * q + q * (q - 1) / 2); };
+    constexpr bool DYN = PERSIST && HM_PERSIST == 2;
     long long pos = 0, pos_end = 0;
-    if (PERSIST) {
+    uint32_t chunk = blockIdx.x;     // DYN: the chunk being processed
+    uint32_t next_raw = 0;           // DYN: destination of the asynchronous counter fetch (wave 0, lane 0)
+    bool next_pending = false;
+    auto chunk_range = [&](uint32_t c) {         // DYN: [pos, pos_end) of chunk c; empty when the sequence is used up
+        const long long c1 = p.p_c1;
+        pos = (long long)c < c1 ? (long long)c * p.p_k1 : c1 * p.p_k1 + ((long long)c - c1) * p.p_k2;
+        pos_end = pos + ((long long)c < c1 ? p.p_k1 : p.p_k2);
+        if (pos_end > p.p_total) pos_end = p.p_total;
+    };
+    if (PERSIST && !DYN) {
         pos = p.p_total * (long long)blockIdx.x / (long long)gridDim.x;
         pos_end = p.p_total * ((long long)blockIdx.x + 1) / (long long)gridDim.x;
         if (pos >= pos_end) return;
@@ -447,7 +479,31 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
         for (int t = threadIdx.x; t < HM_HIST_BINS; t += NTHREADS) lhist[t] = 0;
     }
 
+#if HM_DIAG_TIMES
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t diag_slow = 0, diag_pass = 0, diag_tiles = 0;
+    unsigned long long diag_slow_ticks = 0;
+#endif
+    uint32_t* s_next = reinterpret_cast<uint32_t*>(smem + NBUF * TILE_LDS);     // DYN: next chunk, published by wave 0
+    for (;;) {   // DYN: one pass per chunk taken from the counter; otherwise a single pass
+    if (DYN) {
+        chunk_range(chunk);
+        if (pos >= pos_end) break;               // every wave of the block sees the same chunk: uniform exit
+        // fetch the next chunk now, use it when this one is done: the counter's latency hides behind the
+        // chunk's tiles.  An asm atomic the compiler does not wait for; picked up behind the first tile's
+        // counted wait and published through LDS (read by all waves after this chunk's last barrier).
+        if (wave == 0) {
+            if (lane == 0) {
+                const uint32_t one = 1u;
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(next_raw) : "v"(&p.ctr[5]), "v"(one) : "memory");
+            }
+            next_pending = true;
+        }
+    }
     do {   // one pass per (row block, run of column tiles); a single pass unless PERSIST
+#if HM_DIAG_TIMES
+    ++diag_pass;
+#endif
     int rb, ct0, ct1;
     if (PERSIST) {
         int lo = 0, hi = p.p_nrb - 1;                       // largest q with seq_before(q) <= pos
@@ -758,8 +814,12 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) diag_sum += acc[tm][tn][0];
             }
-            if (HM_DIAG_NO_EPI && BF ? (diag_sum == 12345.0f) : __ballot(ext_u < bound_f) != 0ull) {
+            if (HM_DIAG_NO_EPI && BF ? (diag_sum == 12345.0f) : (__ballot(ext_u < bound_f) != 0ull && !(HM_DIAG_NEVER_SLOW && p.n > 0))) {
                 const bool full = rows_full && (j0 > i0w + WAVE_ROWS - 1) && (j0 + COLS - 1 < p.n);
+#if HM_DIAG_TIMES
+                ++diag_slow;
+                const unsigned long long diag_s0 = __builtin_amdgcn_s_memrealtime();
+#endif
                 // -------- slow path, one 32x32 MFMA tile at a time (a rolled loop: the hot loop must not
                 // inherit its register pressure).  Per-element predicates are evaluated twice (count, then
                 // write); the second evaluation runs on laundered copies of the bounds so that the compiler
@@ -848,8 +908,14 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                     gk = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (wk < gk) gk = wk;
                 }
+#if HM_DIAG_TIMES
+                diag_slow_ticks += __builtin_amdgcn_s_memrealtime() - diag_s0;
+#endif
             }
         }
+#if HM_DIAG_TIMES
+        ++diag_tiles;
+#endif
         if (ALWAYS) {
             // tile t+1 has landed (this wave's pieces) -- and so has the key load, if one was issued
             if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gk_raw) : : "memory");
@@ -863,10 +929,26 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
             if (gk_raw < gk) gk = gk_raw;                   // the key only ever decreases
             gk_pending = false;
         }
+        if (DYN && next_pending) {                           // wave 0, once per chunk: the fetch has returned (vmcnt(0) above)
+            static_assert(!DYN || DIST == 1, "the counter fetch rides on the vmcnt(0) of a two-slot ring");
+            asm volatile("" : "+v"(next_raw) : : "memory");
+            if (lane == 0) *s_next = (uint32_t)gridDim.x + next_raw;
+            next_pending = false;
+        }
         if (!(HM_DIAG_NO_BARRIER && BF)) __syncthreads();   // ... and every wave's; all reads of slot `buf` done
         if (++buf == NBUF) buf = 0;
     }
     } while (PERSIST && pos < pos_end);
+    if (!DYN) break;
+    chunk = __builtin_amdgcn_readfirstlane(*s_next);        // written before a barrier every wave has passed
+    }
+#if HM_DIAG_TIMES
+    if (MODE == HM_MODE_ARGMIN && lane == 0 && (blockIdx.x & 1) == 0 && blockIdx.x / 2 < HM_DIGIT_BINS / 16) {
+        uint32_t* o = p.hist + (blockIdx.x / 2) * 16 + wave * 4;
+        o[0] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - diag_t0);
+        o[1] = wave == 1 ? (uint32_t)diag_t0 : diag_slow; o[2] = (uint32_t)diag_slow_ticks; o[3] = (diag_pass << 16) | diag_tiles;
+    }
+#endif
 
     if (MODE == HM_MODE_TOPK) {
         // one 64-bit atomic per wave for the sure count
@@ -1305,6 +1387,8 @@ struct hm_engine {
     // work-decomposition knobs (defaults from the macros; HM_TUNE_* environment overrides are a tuning aid)
     int chunk_f32 = HM_CHUNK_TILES, chunk_bf16 = HM_CHUNK_TILES_BF16, tail_div = 4;
     double tail_fraction = HM_TAIL_FRACTION;
+    int dyn_k1 = HM_DYN_K1, dyn_k2 = HM_DYN_K2;   // HM_PERSIST == 2: tiles per chunk, early / late part of the sequence
+    double dyn_split = HM_DYN_SPLIT;              // share of the sequence handed out in the larger chunks
     int64_t max_rows = 0, rows_alloc = 0, n = 0;
     int d1 = 0, d = 0, NG = 0, RS = 0, sign_mode = 0;
     float* img = nullptr;
@@ -1416,6 +1500,9 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     }
     if (const char* t = getenv("HM_TUNE_CHUNK")) { const int v = atoi(t); if (v >= 4 && v <= 4096) e->chunk_f32 = e->chunk_bf16 = v; }
     if (const char* t = getenv("HM_TUNE_TAIL")) { const double v = atof(t); if (v >= 0.0 && v <= 0.9) e->tail_fraction = v; }
+    if (const char* t = getenv("HM_TUNE_K1")) { const int v = atoi(t); if (v >= 1 && v <= 4096) e->dyn_k1 = v; }
+    if (const char* t = getenv("HM_TUNE_K2")) { const int v = atoi(t); if (v >= 1 && v <= 4096) e->dyn_k2 = v; }
+    if (const char* t = getenv("HM_TUNE_SPLIT")) { const double v = atof(t); if (v >= 0.0 && v <= 1.0) e->dyn_split = v; }
     if (const char* t = getenv("HM_TUNE_TAIL_DIV")) { const int v = atoi(t); if (v >= 1 && v <= 16) e->tail_div = v; }
     e->ent_cap = 1u << 24;
     e->sorted_cap = 1u << 16;
@@ -1442,8 +1529,9 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     HM_HIP(hipMalloc(&e->d_hist, sizeof(uint32_t) * HM_DIGIT_BINS));
     HM_HIP(hipHostMalloc(&e->h, sizeof(HostCtl), hipHostMallocDefault));
     HM_HIP(hipHostMalloc(&e->h_sorted, sizeof(uint4) * (size_t)e->sorted_cap, hipHostMallocDefault));
-    HM_HIP(hipEventCreate(&e->ev0));
-    HM_HIP(hipEventCreate(&e->ev1));
+    // timing events without the system-scope fence a default event adds around the scan
+    HM_HIP(hipEventCreateWithFlags(&e->ev0, HM_EVENT_FLAGS));
+    HM_HIP(hipEventCreateWithFlags(&e->ev1, HM_EVENT_FLAGS));
     *out = e;
     return HM_OK;
 }
@@ -1556,6 +1644,7 @@ static hipError_t hm_launch_scan_t(const ScanArgs& a, dim3 grid, hipStream_t s)
     const size_t ppw = (tile_bytes / 1024 + WPB - 1) / WPB;
     size_t lds = ((BF ? HM_DIST_BF16 : 1) + 1) * ppw * WPB * 1024;
     if (MODE == HM_MODE_HIST) lds += sizeof(uint32_t) * HM_HIST_BINS;
+    else if (BF && HM_PERSIST == 2) lds += 64;               // the published next-chunk word
     static bool attr_set = false;    // per instantiation
     if (!attr_set && lds > 48 * 1024) {
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void*>(&hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, TN>),
@@ -1710,6 +1799,9 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     a.p_nrb = nrb;
     a.p_total = (long long)nrb * a.nct - (long long)tiles_per_rb * ((long long)a.rb_first * nrb + (long long)nrb * (nrb - 1) / 2);
     a.p_grid = (int)std::max<long long>(1, std::min<long long>((long long)e->n_cu * HM_PERSIST_BLOCKS_PER_CU, a.p_total / 4));
+    a.p_k1 = e->dyn_k1;
+    a.p_k2 = e->dyn_k2;
+    a.p_c1 = (int)((double)a.p_total * e->dyn_split / a.p_k1);
     return true;
 }
 
@@ -1733,6 +1825,16 @@ static void hm_flush_pending_timing(hm_engine* e)
 
 // arguments of hm_post_argmin_final_kernel that describe the seed update
 #define HM_SEED_ARGS(e, a) (e)->d_seed, (e)->img, (e)->RS, (e)->d, (e)->sign_mode, (a).bf16, ((a).bf16 ? 16 * (e)->KS : (e)->RS), (e)->d_rmax2
+
+#if HM_DIAG_TIMES
+extern "C" int hm_debug_read_hist(hm_engine* e, uint32_t* out, int n)
+{
+    HM_HIP(hipSetDevice(e->device));
+    HM_HIP(hipDeviceSynchronize());
+    HM_HIP(hipMemcpy(out, e->d_hist, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return HM_OK;
+}
+#endif
 
 extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end, uint32_t* rec_dev,
                                       void* stream)

@@ -316,11 +316,12 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
             best = found[0]
             self._merge_tokens(best.token_i, best.token_j)
 
-            elapsed = time.time() - t0
-            cs = self.cache.get_stats()
-            bar.set_postfix({"vocab_size": self.current_vocab_size, "best_dist": best.distance,
-                             "threshold": self.merge_threshold, "time": f"{elapsed:.2f}s",
-                             "hit_ratio": f"{cs['hit_ratio']:.2f}"})
+            if not bar.disable:                   # display only (tqdm formats the postfix even when disabled)
+                elapsed = time.time() - t0
+                cs = self.cache.get_stats()
+                bar.set_postfix({"vocab_size": self.current_vocab_size, "best_dist": best.distance,
+                                 "threshold": self.merge_threshold, "time": f"{elapsed:.2f}s",
+                                 "hit_ratio": f"{cs['hit_ratio']:.2f}"})
             if (step + 1) % log_every == 0:
                 logger.info(f"Step {step+1}: merged '{self.vocab[best.token_i]}' + "
                             f"'{self.vocab[best.token_j]}' -> '{self.vocab[-1]}' (dist: {best.distance:.4f})")

@@ -236,7 +236,8 @@ class HyperbolicTokenizer:
                 logger.info(f"Step {step+1}: merged '{self.vocab[i]}' + '{self.vocab[j]}' -> "
                             f"'{self.vocab[-1]}' (dist: {dist:.4f})")
                 logger.info(f"Vocabulary size: {len(self.vocab)}")
-            bar.set_postfix({"vocab_size": len(self.vocab), "best_dist": dist, "threshold": self.merge_threshold})
+            if not bar.disable:                   # display only (tqdm formats the postfix even when disabled)
+                bar.set_postfix({"vocab_size": len(self.vocab), "best_dist": dist, "threshold": self.merge_threshold})
 
     def _evaluate_candidates_parallel(self, candidates: List[Tuple[int, int, float]]) -> Tuple[int, int, float]:
         """Reference ``:553-591``: simulate the merges, then return the first candidate unchanged."""
