@@ -33,3 +33,8 @@ print("duration by even block index (every 8th):", us[::8, 0].round(0))
 print("start offsets sample:", t0[::16].round(1))
 slow = slow.copy(); slow[:, 1] = 0
 print("total slow entries", slow.sum(), "total slow us", sticks.sum() / 100.0, "mean us per entry", sticks.sum() / 100.0 / max(1, slow.sum()))
+tiles = (pt[:, 0] & 0xffff).astype(np.float64); passes = (pt[:, 0] >> 16).astype(np.float64)
+A = np.stack([tiles, passes, np.ones_like(tiles)], 1)
+coef, *_ = np.linalg.lstsq(A, us[:, 0], rcond=None)
+print("fit: block us = %.3f * tiles + %.3f * passes + %.1f   (tiles %d..%d, passes %d..%d)" % (coef[0], coef[1], coef[2], tiles.min(), tiles.max(), passes.min(), passes.max()))
+print("sum tiles (sampled even blocks)", tiles.sum(), "sum passes", passes.sum())
