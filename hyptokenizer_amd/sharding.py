@@ -57,6 +57,12 @@ class ShardContext:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         self.device = torch.device(device)
+        # buffers of the per-step record exchange, allocated once (the step is latency-bound)
+        self._rec = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._recs = torch.zeros(4 * self.world, dtype=torch.int32, device=self.device)
+        self._host = torch.zeros(4 * self.world, dtype=torch.int32)
+        if self.device.type == "cuda":
+            self._host = self._host.pin_memory()
 
     def row_range(self, n: int) -> Tuple[int, int]:
         b = partition_rows(n, self.world)
@@ -121,11 +127,11 @@ def sharded_argmin(engine, ctx: ShardContext, c: float, thr: float):
     over RCCL on the same stream -> one 16*world-byte read-back."""
     r0, r1 = ctx.row_range(engine.n)
     if hasattr(engine, "argmin_into") and ctx.device.type == "cuda":
-        rec = torch.empty(4, dtype=torch.int32, device=ctx.device)
-        engine.argmin_into(c, thr, r0, r1, rec)
-        out = torch.empty(4 * ctx.world, dtype=torch.int32, device=ctx.device)
-        dist.all_gather_into_tensor(out, rec, group=ctx.group)
-        recs = out.cpu().numpy().reshape(ctx.world, 4)
+        engine.argmin_into(c, thr, r0, r1, ctx._rec)
+        dist.all_gather_into_tensor(ctx._recs, ctx._rec, group=ctx.group)
+        ctx._host.copy_(ctx._recs, non_blocking=True)
+        torch.cuda.current_stream(ctx.device).synchronize()
+        recs = ctx._host.numpy().reshape(ctx.world, 4)
         if not (recs[:, 0] == 2).any():
             return _best_of_records(recs)
         # some rank overflowed its emission buffer (tie flood): every rank takes the bounded host path
