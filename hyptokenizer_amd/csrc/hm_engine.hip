@@ -140,7 +140,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_DIST_BF16 1             // bf16 form: tiles in flight ahead of the computed one (ring of DIST + 1 slots; deeper rings measured no gain)
 #endif
 #ifndef HM_TN_BF16
-#define HM_TN_BF16 2               // bf16 form: 64 partner rows per streamed tile
+#define HM_TN_BF16 1               // bf16 form: 32-column MFMA tiles per accumulator group
+#endif
+#ifndef HM_SUB_BF16
+#define HM_SUB_BF16 2              // bf16 form: a streamed tile (64 partner rows) is walked as SUB groups of 32 * TN columns,
+                                   // accumulators reused: 64x32 outputs per wave and group, 149 VGPRs
+#endif
+#ifndef HM_MIN_WAVES_BF16
+#define HM_MIN_WAVES_BF16 2        // bf16 form: blocks per CU the register budget is sized for
 #endif
 #ifndef HM_WPB_BF16
 #define HM_WPB_BF16 4              // bf16 form: waves per block (all share each streamed 64-row tile)
@@ -424,9 +431,11 @@ __device__ __forceinline__ void hm_dma_run(const char* src, uint32_t dst)
 // canonical arithmetic, and the bound `delta` on |u_f - u_c| widens every comparison accordingly.
 // TM = 32-row MFMA tiles per wave along the stationary rows (block = 4 waves = 128*TM rows).
 template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int TN>
-__global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const ScanArgs p)
+__global__ __launch_bounds__(64 * WPB, BF ? HM_MIN_WAVES_BF16 : HM_MIN_WAVES) void hm_scan_kernel(const ScanArgs p)
 {
-    constexpr int COLS = 32 * TN;                  // partner rows per streamed tile (TN 32-column MFMA tiles)
+    constexpr int SUB = BF ? HM_SUB_BF16 : 1;      // column groups per streamed tile
+    constexpr int SCOLS = 32 * TN;                 // columns per group (TN 32-column MFMA tiles)
+    constexpr int COLS = SCOLS * SUB;              // partner rows per streamed tile
     constexpr int RS = hm_row_floats(NG);          // fp32 image: floats per row
     constexpr int RB16 = 32 * NG + 16;             // bf16 image: bytes per row (NG x 16 bf16 + [x0 fp32, pad])
     constexpr int TILE_BYTES = BF ? COLS * RB16 : COLS * RS * 4;
@@ -696,8 +705,12 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                 for (int q = NP; q < PPW; ++q) dma_piece(ct_next, buf_next, q * WPB + wave);
             }
         }
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub) {
+        const int j0s = j0 + sub * SCOLS;
+        const bool compute_s = wave_active && (j0s + SCOLS - 1 > i0w);
         f32x16 acc[TM][TN];
-        if (compute) {
+        if (compute_s) {
             // running best key of the argmin search, refreshed every 8th tile only: hipcc waits for
             // this vector load with vmcnt(0), which also drains the LDS-DMA ring.  A stale key only
             // emits a few more entries.
@@ -712,7 +725,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
 
             if constexpr (BF) {
                 // bf16 prefilter: S = sum over the spatial coordinates, 16 per MFMA, fp32 accumulate
-                const char* bt = smem + buf * TILE_LDS + r * RB16 + 16 * h;
+                const char* bt = smem + buf * TILE_LDS + (sub * SCOLS + r) * RB16 + 16 * h;
                 uint4 bc[TN], bn[TN];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) bc[tn] = *reinterpret_cast<const uint4*>(bt + 32 * tn * RB16);
@@ -740,7 +753,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
             } else {
                 static_assert(BF || TN == 2, "the fp32 form is written for two 32-column tiles per streamed tile");
                 // B fragments (optionally fetched one k-group ahead of the MFMAs that consume them)
-                const float* bt = reinterpret_cast<const float*>(smem + buf * TILE_LDS) + r * RS + 2 * h;
+                const float* bt = reinterpret_cast<const float*>(smem + buf * TILE_LDS) + (sub * SCOLS + r) * RS + 2 * h;
 #if HM_PREFETCH_B
                 float2 b0 = *reinterpret_cast<const float2*>(bt);
                 float2 b1 = *reinterpret_cast<const float2*>(bt + 32 * RS);
@@ -815,7 +828,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                     for (int tn = 0; tn < TN; ++tn) diag_sum += acc[tm][tn][0];
             }
             if (HM_DIAG_NO_EPI && BF ? (diag_sum == 12345.0f) : (__ballot(ext_u < bound_f) != 0ull && !(HM_DIAG_NEVER_SLOW && p.n > 0))) {
-                const bool full = rows_full && (j0 > i0w + WAVE_ROWS - 1) && (j0 + COLS - 1 < p.n);
+                const bool full = rows_full && (j0s > i0w + WAVE_ROWS - 1) && (j0s + SCOLS - 1 < p.n);
 #if HM_DIAG_TIMES
                 ++diag_slow;
                 const unsigned long long diag_s0 = __builtin_amdgcn_s_memrealtime();
@@ -827,12 +840,12 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                 unsigned long long wkey = ~0ull;
                 bool wrote = false;
 #pragma unroll 1
-                for (int sub = 0; sub < (HM_DIAG_NO_SLOW ? 0 : TM * TN); ++sub) {
+                for (int st = 0; st < (HM_DIAG_NO_SLOW ? 0 : TM * TN); ++st) {
                     f32x16 w = acc[0][0];
 #pragma unroll
                     for (int q = 1; q < TM * TN; ++q)
-                        if (sub == q) w = acc[q / TN][q % TN];
-                    const int tm = sub / TN, tn = sub - tm * TN;
+                        if (st == q) w = acc[q / TN][q % TN];
+                    const int tm = st / TN, tn = st - tm * TN;
                     if (TM * TN > 1) {
                         float e1 = w[0];
 #pragma unroll
@@ -844,7 +857,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                     float cutv = cut_f;
                     uint32_t slot = 0;
                     const int ib = i0w + 32 * tm + 4 * h;
-                    const int j = j0 + 32 * tn + r;
+                    const int j = j0s + 32 * tn + r;
                     auto visit = [&](const float wv, const int e, const bool write) {
                         const float u = SIGN ? -wv : wv;
                         const int i = ib + (e & 3) + 8 * (e >> 2);
@@ -912,6 +925,7 @@ __global__ __launch_bounds__(64 * WPB, HM_MIN_WAVES) void hm_scan_kernel(const S
                 diag_slow_ticks += __builtin_amdgcn_s_memrealtime() - diag_s0;
 #endif
             }
+        }
         }
 #if HM_DIAG_TIMES
         ++diag_tiles;
@@ -1640,7 +1654,7 @@ static Bounds hm_bounds(float thr, float c)
 template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int TN>
 static hipError_t hm_launch_scan_t(const ScanArgs& a, dim3 grid, hipStream_t s)
 {
-    const size_t tile_bytes = BF ? (size_t)32 * TN * (32 * NG + 16) : sizeof(float) * 32 * TN * hm_row_floats(NG);
+    const size_t tile_bytes = BF ? (size_t)32 * TN * HM_SUB_BF16 * (32 * NG + 16) : sizeof(float) * 32 * TN * hm_row_floats(NG);
     const size_t ppw = (tile_bytes / 1024 + WPB - 1) / WPB;
     size_t lds = ((BF ? HM_DIST_BF16 : 1) + 1) * ppw * WPB * 1024;
     if (MODE == HM_MODE_HIST) lds += sizeof(uint32_t) * HM_HIST_BINS;
@@ -1722,7 +1736,7 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     a.img16 = e->img16;
     a.bf16 = hm_use_bf16(e) ? 1 : 0;
     const int block_rows = a.bf16 ? 32 * HM_TM_BF16 * HM_WPB_BF16 : 128 * HM_TM_F32;
-    const int cols = a.bf16 ? 32 * HM_TN_BF16 : 64;              // partner rows per streamed tile
+    const int cols = a.bf16 ? 32 * HM_TN_BF16 * HM_SUB_BF16 : 64;   // partner rows per streamed tile
     a.n = (int)e->n;
     a.row_begin = (int)row_begin;
     a.row_end = (int)row_end;
