@@ -6,20 +6,29 @@
 // plus the log-map / exp-map "midpoint" of _merge_tokens (hyperbolic_merge.py:326-340).
 //
 // Kernel inventory
-//   hm_scan_kernel      pair scan: X.G.X^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact
-//                       fmaf chain), A rows stationary in registers, partner rows streamed through
-//                       LDS by LDS-DMA, epilogue = prefilter on the acosh argument + wave-aggregated
-//                       emission of survivors.  Never materialises the N x N matrix.
+//   hm_scan_kernel      pair scan: X.G.X^T on the matrix cores as a PREFILTER -- bf16 form
+//                       (v_mfma_f32_32x32x16_bf16 on a bf16 image, default for d >= 24) or fp32 form
+//                       (v_mfma_f32_32x32x2_f32, exact fmaf chain) -- stationary rows in registers,
+//                       partner rows streamed through LDS by LDS-DMA, epilogue = bound test on the
+//                       acosh argument (widened by a rigorous error bound, hm_scan_delta) +
+//                       wave-aggregated emission of survivors.  Never materialises the N x N matrix.
 //   hm_post_*           exact canonical distance for the survivors, threshold test, exact
 //                       (d, i, j) selection (min / radix narrowing / rank sort).
-//   hm_midpoint_kernel  batched log-map -> scale -> exp-map -> project.
-//   hm_pairdist_kernel, hm_rowvsall_kernel, hm_dense_kernel, hm_rows_* : gathered / dense forms.
+//   hm_seed_init_kernel counters + running-key seed of an argmin search (previous nearest pair).
+//   hm_midpoint_kernel, hm_merge_append_kernel   log-map -> scale -> exp-map -> project.
+//   hm_row_argmin_kernel, hm_pairdist_kernel, hm_rowvsall_kernel, hm_dense_kernel, hm_rows_* :
+//                       one-vs-all / gathered / dense forms on the canonical arithmetic.
 //
-// Data layout in HBM: the "scan image" img[rows_alloc][RS] fp32, RS = 4*NG + 4, NG = groups of 4
-// spatial coordinates.  Group g holds spatial coordinates s = 4g..4g+3 in the order
-// [s0, s2, s1, s3] so that lane-half h of a wave reads ONE 8-byte word (position 2h) holding its
-// operands for the two MFMA k-steps of the group; the last group is [x0, 0, 0, 0] (time).
-// A 64-row tile of the image is one contiguous block of (NG+1) KiB.
+// Data layout in HBM: the fp32 "scan image" img[rows_alloc][RS], RS = 4*NG + 4 (+ 4 when needed to
+// make the 16-byte chunks per row odd), NG = groups of 4 spatial coordinates.  Group g holds spatial
+// coordinates s = 4g..4g+3 in the order [s0, s2, s1, s3] so that lane-half h of a wave reads ONE
+// 8-byte word (position 2h) holding its operands for the two MFMA k-steps of the group; the time
+// chunk [x0, 0, 0, 0] is last.  The bf16 image img16[rows_alloc][32*KS + 16 bytes]: KS k-steps of 16
+// bf16 (spatial coordinates, then the time coordinate split hi + lo in the last four slots) and a
+// trailing chunk [x0 fp32, 0, 0, 0] (odd chunk count: conflict-free ds_read_b128).  A 64-row tile of
+// either image is one contiguous block -> LDS-DMA in 1 KiB pieces, no padding.
+// The macros below are compile-time knobs; the ones marked "experiment" are measured dead ends kept
+// for the record, HM_DIAG_* are timing diagnostics that break the results.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -109,17 +118,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_DIAG_NO_MFMA 0
 #endif
 #ifndef HM_EVENT_FLAGS
-#define HM_EVENT_FLAGS hipEventDisableSystemFence
+#define HM_EVENT_FLAGS hipEventDisableSystemFence   // scan timing events: no system-scope fence around the launch
 #endif
 #ifndef HM_PERSIST
 #define HM_PERSIST 0               // experiment (off): bf16 form, one resident block per slot walks an equal share of the
                                    // tile sequence -- no launch tail, but measured 50 % slower than the chunked grid
 #endif
 #ifndef HM_DYN_K1
-#define HM_DYN_K1 32
+#define HM_DYN_K1 32               // experiment (HM_PERSIST == 2): tiles per chunk taken from the atomic counter, early part
 #endif
 #ifndef HM_DYN_K2
-#define HM_DYN_K2 8
+#define HM_DYN_K2 8                // ... and late part of the tile sequence
 #endif
 #ifndef HM_DYN_SPLIT
 #define HM_DYN_SPLIT 0.8
@@ -128,7 +137,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_PERSIST_BLOCKS_PER_CU 2
 #endif
 #ifndef HM_SETTLE_PROLOGUE
-#define HM_SETTLE_PROLOGUE 1
+#define HM_SETTLE_PROLOGUE 1       // compiler-visible vmcnt(0) before the tile loop (keeps hipcc's lazy waits out of it)
 #endif
 #ifndef HM_DMA_GROUPED
 #define HM_DMA_GROUPED 1           // bf16 form: LDS-DMA pieces issued four per statement, unconditionally (see hm_dma_group)
