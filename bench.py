@@ -26,6 +26,7 @@ the same search on a bounded row sample on this host's cores (rank 0, N = 1 only
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -137,6 +138,10 @@ def main() -> None:
     torch.cuda.synchronize()
 
     def barrier():
+        # a generation-2 collection over three 50k-token vocabularies is a 50 ms host stall: collect between the
+        # legs and park the survivors, so that no leg's clock is charged for it
+        gc.collect()
+        gc.freeze()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

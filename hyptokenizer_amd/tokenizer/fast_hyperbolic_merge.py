@@ -92,11 +92,26 @@ class AdaptiveMergeCache:
         self._list: List[MergeCandidate] = []     # materialised entries (always in front of the arrays)
         self._arr = None                          # (d, i, j) arrays of not-yet-materialised entries
         self._pos = 0
-        self.hit_count: Dict[Tuple[int, int], int] = {}
+        self._hit_count: Dict[Tuple[int, int], int] = {}
+        self._served: List[Tuple[np.ndarray, np.ndarray]] = []   # (i, j) arrays of batches served straight from the arrays
         self.miss_count: int = 0
         self._hits = 0                            # running sum(hit_count.values())
 
-    # -- the reference's public attribute -------------------------------------------------------
+    # -- the reference's public attributes ------------------------------------------------------
+    @property
+    def hit_count(self) -> Dict[Tuple[int, int], int]:
+        """served pairs -> times served; batches popped as arrays are folded in when this is read"""
+        for ii, jj in self._served:
+            for key in zip(ii.tolist(), jj.tolist()):
+                self._hit_count[key] = self._hit_count.get(key, 0) + 1
+        self._served = []
+        return self._hit_count
+
+    @hit_count.setter
+    def hit_count(self, value) -> None:
+        self._hit_count = dict(value)
+        self._served = []
+
     @property
     def candidates(self) -> List[MergeCandidate]:
         self._materialise_all()
@@ -143,17 +158,31 @@ class AdaptiveMergeCache:
         merged.sort()                       # stable, by distance only
         self.candidates = merged[: self.max_size]
 
-    def get_best(self, n: int = 1) -> List[MergeCandidate]:
+    def get_best(self, n: int = 1):
+        """Pop the first n entries.  Served straight from the refresh's arrays when nothing has been
+        materialised: the batch is then a ``CandidateList`` (same ``len`` / indexing / iteration as the
+        reference's list) -- the merge loop only ever looks at entry 0 of the 100 it pops."""
         if len(self) == 0:
             self.miss_count += 1
             return []
+        if not self._list and self._arr is not None:
+            d, i, j = self._arr
+            lo = self._pos
+            hi = min(lo + n, len(d))
+            self._pos = hi
+            if hi >= len(d):
+                self._arr, self._pos = None, 0
+            self._served.append((i[lo:hi], j[lo:hi]))
+            self._hits += hi - lo
+            return CandidateList(d[lo:hi], i[lo:hi], j[lo:hi], hi - lo)
         best = self._list[:n]
         self._list = self._list[n:]
         if len(best) < n:
             best = best + self._take(n - len(best))
+        hc = self.hit_count
         for cand in best:
             key = (cand.token_i, cand.token_j)
-            self.hit_count[key] = self.hit_count.get(key, 0) + 1
+            hc[key] = hc.get(key, 0) + 1
         self._hits += len(best)
         return best
 

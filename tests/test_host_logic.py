@@ -180,6 +180,31 @@ def test_cpu_search_raises_without_engine():
         ftok.optimize_merges(steps=1)
 
 
+def test_cache_lazy_batches_keep_reference_semantics():
+    """batches served straight from a refresh's arrays behave like the reference's popped lists:
+    same entries, same bookkeeping (hit_count per served pair, stats), mixing with materialised
+    entries falls back to lists"""
+    d = np.array([0.1, 0.2, 0.2, 0.3, 0.4], np.float32)
+    i = np.array([0, 1, 2, 3, 4], np.int32)
+    j = np.array([5, 6, 7, 8, 9], np.int32)
+    cache = AdaptiveMergeCache(max_size=4)
+    cache.add_batch(CandidateList(d, i, j, 5))
+    assert len(cache) == 4                                   # truncated to max_size
+    first = cache.get_best(2)
+    assert len(first) == 2 and bool(first) and first[0] == MergeCandidate(float(d[0]), 0, 5)
+    assert [(c.token_i, c.token_j) for c in first] == [(0, 5), (1, 6)]
+    assert cache.hit_count == {(0, 5): 1, (1, 6): 1} and cache.get_stats()["hit_count"] == 2
+    assert [c.token_i for c in cache.candidates] == [2, 3]   # reading the attribute materialises the rest
+    rest = cache.get_best(100)                               # ... and later pops are plain lists
+    assert isinstance(rest, list) and [c.token_i for c in rest] == [2, 3]
+    assert cache.hit_count[(2, 7)] == 1 and cache.get_stats()["hit_count"] == 4 and len(cache) == 0
+    assert cache.get_best(1) == [] and cache.miss_count == 1
+    # served twice -> counted twice
+    cache.add_batch(CandidateList(d[:1], i[:1], j[:1], 1))
+    cache.get_best(1)
+    assert cache.hit_count[(0, 5)] == 2
+
+
 def test_incremental_state_invalidation():
     """the running minimum is recomputed when the threshold moves, the table is edited, or the
     search crosses the reference's n <= 100 compare branch; otherwise one row pass per step"""
