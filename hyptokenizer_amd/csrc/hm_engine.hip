@@ -1001,7 +1001,7 @@ __device__ __forceinline__ bool hm_key_less(uint32_t a0, uint32_t a1, uint32_t a
 
 // canonical distance of every entry, threshold, lexicographic min of (dbits, i, j).
 // Stage 1: HM_ARGMIN_BLOCKS blocks, one partial record each; stage 2: one block over the partials.
-#define HM_ARGMIN_BLOCKS 64
+#define HM_ARGMIN_BLOCKS 256
 struct ArgminPart { uint32_t dbits, i, j, pad; };
 
 __device__ __forceinline__ void hm_block_min_key(uint32_t& b0, uint32_t& b1, uint32_t& b2, uint32_t* s0, uint32_t* s1, uint32_t* s2)
