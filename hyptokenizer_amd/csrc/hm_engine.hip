@@ -158,6 +158,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef HM_MIN_WAVES_BF16
 #define HM_MIN_WAVES_BF16 2        // bf16 form: blocks per CU the register budget is sized for
 #endif
+#ifndef HM_TM4_MIN_ROWS
+#define HM_TM4_MIN_ROWS 80000      // bf16 form: from this many live rows on, 128 stationary rows per wave (512-row blocks)
+#endif
 #ifndef HM_WPB_BF16
 #define HM_WPB_BF16 4              // bf16 form: waves per block (all share each streamed 64-row tile)
 #endif
@@ -182,6 +185,7 @@ struct ScanArgs {
     const float* img;
     const unsigned char* img16;   // bf16 image (BF = 1 kernels)
     int bf16;                     // host-side: which form this launch uses
+    int tm4;                      // host-side: bf16 form with 128 stationary rows per wave (512-row blocks; large tables)
     int n;                  // live rows
     int row_begin, row_end; // i range
     int rb_first;           // first row block
@@ -1410,6 +1414,7 @@ struct hm_engine {
     // work-decomposition knobs (defaults from the macros; HM_TUNE_* environment overrides are a tuning aid)
     int chunk_f32 = HM_CHUNK_TILES, chunk_bf16 = HM_CHUNK_TILES_BF16, tail_div = 4;
     double tail_fraction = HM_TAIL_FRACTION;
+    int64_t tm4_min_rows = HM_TM4_MIN_ROWS;       // bf16 form: tables at least this large use 512-row blocks
     int dyn_k1 = HM_DYN_K1, dyn_k2 = HM_DYN_K2;   // HM_PERSIST == 2: tiles per chunk, early / late part of the sequence
     double dyn_split = HM_DYN_SPLIT;              // share of the sequence handed out in the larger chunks
     int64_t max_rows = 0, rows_alloc = 0, n = 0;
@@ -1526,6 +1531,7 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     if (const char* t = getenv("HM_TUNE_K1")) { const int v = atoi(t); if (v >= 1 && v <= 4096) e->dyn_k1 = v; }
     if (const char* t = getenv("HM_TUNE_K2")) { const int v = atoi(t); if (v >= 1 && v <= 4096) e->dyn_k2 = v; }
     if (const char* t = getenv("HM_TUNE_SPLIT")) { const double v = atof(t); if (v >= 0.0 && v <= 1.0) e->dyn_split = v; }
+    if (const char* t = getenv("HM_TUNE_TM4_ROWS")) { const long v = atol(t); if (v >= 0) e->tm4_min_rows = v; }
     if (const char* t = getenv("HM_TUNE_TAIL_DIV")) { const int v = atoi(t); if (v >= 1 && v <= 16) e->tail_div = v; }
     e->ent_cap = 1u << 24;
     e->sorted_cap = 1u << 16;
@@ -1705,6 +1711,15 @@ static bool hm_use_bf16(const hm_engine* e)
 static hipError_t hm_launch_scan(const hm_engine* e, int mode, const ScanArgs& a, dim3 grid, hipStream_t s)
 {
     if (a.bf16 && HM_PERSIST && mode != HM_MODE_HIST) grid = dim3((unsigned)a.p_grid, 1, 1);
+    if (a.bf16 && a.tm4) {
+        switch (e->KS) {
+            case 1: return hm_launch_scan_ng<1, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
+            case 2: return hm_launch_scan_ng<2, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
+            case 4: return hm_launch_scan_ng<4, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
+            case 7: return hm_launch_scan_ng<7, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
+        }
+        return hipErrorInvalidValue;
+    }
     if (a.bf16) {
         switch (e->KS) {
             case 1: return hm_launch_scan_ng<1, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
@@ -1734,6 +1749,8 @@ static hipError_t hm_launch_scan(const hm_engine* e, int mode, const ScanArgs& a
 }
 
 // common argument preparation; returns false when the row range is empty
+static int64_t hm_pairs_in_range(int64_t n, int64_t r0, int64_t r1);
+
 static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t row_end, ScanArgs& a, dim3& grid)
 {
     if (row_end < 0 || row_end > e->n) row_end = e->n;
@@ -1744,7 +1761,12 @@ static bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, in
     a.img = e->img;
     a.img16 = e->img16;
     a.bf16 = hm_use_bf16(e) ? 1 : 0;
-    const int block_rows = a.bf16 ? 32 * HM_TM_BF16 * HM_WPB_BF16 : 128 * HM_TM_F32;
+    // large tables: 512-row blocks halve the L2 -> LDS fill traffic, which is what limits the bf16 form once the
+    // launch tail no longer does (measured +7 % at 100 k rows, -4 % at 50 k); KS = 8 would not fit the registers
+    // (decided by the pairs this launch covers: a row-range search of a sharded run is a small launch)
+    a.tm4 = (a.bf16 && HM_TM_BF16 == 2 && e->KS <= 7 &&
+             hm_pairs_in_range(e->n, row_begin, row_end) >= e->tm4_min_rows * (e->tm4_min_rows - 1) / 2) ? 1 : 0;
+    const int block_rows = a.bf16 ? 32 * (a.tm4 ? 4 : HM_TM_BF16) * HM_WPB_BF16 : 128 * HM_TM_F32;
     const int cols = a.bf16 ? 32 * HM_TN_BF16 * HM_SUB_BF16 : 64;   // partner rows per streamed tile
     a.n = (int)e->n;
     a.row_begin = (int)row_begin;
