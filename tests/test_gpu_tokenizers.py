@@ -139,6 +139,19 @@ def test_full_size_properties(V, d):
         assert np.all((pi >= r0) & (pi < r1))
     assert tot == cnt
     assert sorted(merged)[: len(key)] == key
+    if V >= 100000:
+        # ranges large enough for the 512-row-block form of the scan, with ragged ends inside a block
+        tot2, merged2 = 0, []
+        for r0, r1 in ((0, 777), (777, 90001), (90001, V)):
+            pd, pi, pj, pc = eng.topk(1.0, thr, 10000, r0, r1)
+            tot2 += pc
+            merged2 += list(zip(bits(pd).tolist(), pi.tolist(), pj.tolist()))
+            assert np.all((pi >= r0) & (pi < r1))
+            a2 = eng.argmin(1.0, thr, r0, r1)
+            assert (a2 is None) == (pc == 0)
+            if a2:
+                assert (int(bits([a2[0]])[0]), a2[1], a2[2]) == (int(bits(pd)[0]), int(pi[0]), int(pj[0]))
+        assert tot2 == cnt and sorted(merged2)[: len(key)] == key
     # second refresh uses the predicted cut: same answer
     dd2, ii2, jj2, cnt2 = eng.topk(1.0, thr, 10000)
     assert cnt2 == cnt and np.array_equal(ii2, ii) and np.array_equal(jj2, jj) and np.array_equal(bits(dd2), bits(dd))
