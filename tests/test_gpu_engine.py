@@ -16,12 +16,17 @@ from hyptokenizer_amd.synthetic import lorentz_table  # noqa: E402
 MODES = {"reference": 0, "lorentz": 1}
 
 
-@pytest.fixture(params=["f32", "bf16"], autouse=True)
+@pytest.fixture(params=["f32", "bf16", "bf16-512"], autouse=True)
 def prefilter_form(request, monkeypatch):
-    """Every test in this module runs twice: exact fp32 MFMA prefilter and bf16 MFMA prefilter
-    (HM_SCAN_PRECISION is read when an engine is created).  Results must be identical: the
-    prefilter only selects survivors, the canonical arithmetic decides."""
-    monkeypatch.setenv("HM_SCAN_PRECISION", request.param)
+    """Every test in this module runs three times: exact fp32 MFMA prefilter, bf16 MFMA prefilter, and
+    the bf16 prefilter in its large-table shape (512-row blocks, forced here at every size; both knobs
+    are read when an engine is created).  Results must be identical: the prefilter only selects
+    survivors, the canonical arithmetic decides."""
+    monkeypatch.setenv("HM_SCAN_PRECISION", request.param.split("-")[0])
+    if request.param.endswith("-512"):
+        monkeypatch.setenv("HM_TUNE_TM4_ROWS", "2")
+    else:
+        monkeypatch.delenv("HM_TUNE_TM4_ROWS", raising=False)
     return request.param
 
 
