@@ -1,0 +1,86 @@
+"""GPU: two ranks sharing the one MI355X of the test box, real engines, records exchanged over gloo.
+
+The N-GPU run uses the same code with RCCL (``backend="nccl"``) and one GPU per rank; what is checked
+here is everything except the transport: row ranges of the real scan kernels, per-rank running-key
+seeds, replicated deterministic merges -- the sharded loops must reproduce the single-process merge
+sequence and rows bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+N, D, THR = 6000, 40, 0.55
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(shard):
+    import random
+    from hyptokenizer_amd.synthetic import cjk_vocab, lorentz_table
+    from hyptokenizer_amd.tokenizer.fast_hyperbolic_merge import FastHyperbolicTokenizer
+    from hyptokenizer_amd.tokenizer.hyperbolic_merge import HyperbolicTokenizer
+    dev = torch.device("cuda", 0)
+    X = lorentz_table(N, D, seed=42, scale=0.05)
+    out = {}
+    tok = HyperbolicTokenizer(cjk_vocab(N), torch.nn.Parameter(X.clone()), merge_threshold=THR, device=dev, max_vocab_size=N + 512,
+                              sign_convention="lorentz", shard=shard)
+    tok.optimize_merges(steps=40, log_every=10 ** 9)
+    out["std_merges"] = list(tok.merge_history)
+    out["std_rows"] = tok.embeddings.data[N:tok.current_vocab_size].cpu().numpy().view(np.uint32).tolist()
+    random.seed(42)
+    ftok = FastHyperbolicTokenizer(cjk_vocab(N), torch.nn.Parameter(X.clone()), merge_threshold=THR, device=dev,
+                                   max_vocab_size=N + 512, sign_convention="lorentz", shard=shard, cache_size=500)
+    ftok.optimize_merges(steps=230, log_every=1000)
+    out["fast_merges"] = list(ftok.merge_history)
+    out["fast_thr"] = ftok.merge_threshold
+    itok = HyperbolicTokenizer(cjk_vocab(N), torch.nn.Parameter(X.clone()), merge_threshold=THR, device=dev, max_vocab_size=N + 512,
+                               sign_convention="lorentz", shard=shard, incremental=True)
+    itok.optimize_merges(steps=40, log_every=10 ** 9)
+    out["incr_merges"] = list(itok.merge_history)
+    return out
+
+
+def _worker(rank, world, port, q):
+    os.environ["TQDM_DISABLE"] = "1"
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hyptokenizer_amd.sharding import ShardContext
+        q.put((rank, _run(ShardContext())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_run():
+    os.environ["TQDM_DISABLE"] = "1"
+    ref = _run(None)
+    assert len(ref["std_merges"]) == 40 and len(ref["fast_merges"]) == 230 and ref["incr_merges"] == ref["std_merges"]
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert results[r] == ref, r
