@@ -30,6 +30,7 @@
 // The macros below are compile-time knobs; the ones marked "experiment" are measured dead ends kept
 // for the record, HM_DIAG_* are timing diagnostics that break the results.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -1667,7 +1668,7 @@ static Bounds hm_bounds(float thr, float c)
 }
 
 template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int TN>
-static hipError_t hm_launch_scan_t(const ScanArgs& a, dim3 grid, hipStream_t s)
+static hipError_t hm_launch_scan_t(const ScanArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     const size_t tile_bytes = BF ? (size_t)32 * TN * HM_SUB_BF16 * (32 * NG + 16) : sizeof(float) * 32 * TN * hm_row_floats(NG);
     const size_t ppw = (tile_bytes / 1024 + WPB - 1) / WPB;
@@ -1681,21 +1682,24 @@ static hipError_t hm_launch_scan_t(const ScanArgs& a, dim3 grid, hipStream_t s)
         if (st != hipSuccess) return st;
         attr_set = true;
     }
-    hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, TN>), grid, dim3(64 * WPB), lds, s, a);
+    // timed launches carry their events in the dispatch itself (start / stop timestamps of this kernel): a pair of
+    // hipEventRecord calls around it costs two ~6 us bubbles on the stream
+    if (ev0 != nullptr) hipExtLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, TN>), grid, dim3(64 * WPB), lds, s, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, TN>), grid, dim3(64 * WPB), lds, s, a);
     return hipGetLastError();
 }
 
 template <int NG, int BF, int TM, int WPB, int TN>
-static hipError_t hm_launch_scan_ng(int sign, int mode, const ScanArgs& a, dim3 grid, hipStream_t s)
+static hipError_t hm_launch_scan_ng(int sign, int mode, const ScanArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
     if (sign) {
-        if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 1, HM_MODE_TOPK, BF, TM, WPB, TN>(a, grid, s);
-        if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 1, HM_MODE_ARGMIN, BF, TM, WPB, TN>(a, grid, s);
-        return hm_launch_scan_t<NG, 1, HM_MODE_HIST, BF, TM, WPB, TN>(a, grid, s);
+        if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 1, HM_MODE_TOPK, BF, TM, WPB, TN>(a, grid, s, ev0, ev1);
+        if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 1, HM_MODE_ARGMIN, BF, TM, WPB, TN>(a, grid, s, ev0, ev1);
+        return hm_launch_scan_t<NG, 1, HM_MODE_HIST, BF, TM, WPB, TN>(a, grid, s, ev0, ev1);
     }
-    if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 0, HM_MODE_TOPK, BF, TM, WPB, TN>(a, grid, s);
-    if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 0, HM_MODE_ARGMIN, BF, TM, WPB, TN>(a, grid, s);
-    return hm_launch_scan_t<NG, 0, HM_MODE_HIST, BF, TM, WPB, TN>(a, grid, s);
+    if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 0, HM_MODE_TOPK, BF, TM, WPB, TN>(a, grid, s, ev0, ev1);
+    if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 0, HM_MODE_ARGMIN, BF, TM, WPB, TN>(a, grid, s, ev0, ev1);
+    return hm_launch_scan_t<NG, 0, HM_MODE_HIST, BF, TM, WPB, TN>(a, grid, s, ev0, ev1);
 }
 
 // Which prefilter form a scan uses.  The bf16 form's error bound 0.00392 * max||x_s||^2 only costs
@@ -1708,42 +1712,43 @@ static bool hm_use_bf16(const hm_engine* e)
     return e->d >= 24 && e->bf16_ok;
 }
 
-static hipError_t hm_launch_scan(const hm_engine* e, int mode, const ScanArgs& a, dim3 grid, hipStream_t s)
+static hipError_t hm_launch_scan(const hm_engine* e, int mode, const ScanArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0 = nullptr,
+                                 hipEvent_t ev1 = nullptr)
 {
     if (a.bf16 && HM_PERSIST && mode != HM_MODE_HIST) grid = dim3((unsigned)a.p_grid, 1, 1);
     if (a.bf16 && a.tm4) {
         switch (e->KS) {
-            case 1: return hm_launch_scan_ng<1, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
-            case 2: return hm_launch_scan_ng<2, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
-            case 4: return hm_launch_scan_ng<4, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
-            case 7: return hm_launch_scan_ng<7, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
+            case 1: return hm_launch_scan_ng<1, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 2: return hm_launch_scan_ng<2, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 4: return hm_launch_scan_ng<4, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 7: return hm_launch_scan_ng<7, 1, 4, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s, ev0, ev1);
         }
         return hipErrorInvalidValue;
     }
     if (a.bf16) {
         switch (e->KS) {
-            case 1: return hm_launch_scan_ng<1, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
-            case 2: return hm_launch_scan_ng<2, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
-            case 4: return hm_launch_scan_ng<4, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
-            case 7: return hm_launch_scan_ng<7, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
-            case 8: return hm_launch_scan_ng<8, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s);
+            case 1: return hm_launch_scan_ng<1, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 2: return hm_launch_scan_ng<2, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 4: return hm_launch_scan_ng<4, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 7: return hm_launch_scan_ng<7, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 8: return hm_launch_scan_ng<8, 1, HM_TM_BF16, HM_WPB_BF16, HM_TN_BF16>(e->sign_mode, mode, a, grid, s, ev0, ev1);
         }
         return hipErrorInvalidValue;
     }
     switch (e->NG) {
-        case 1: return hm_launch_scan_ng<1, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 2: return hm_launch_scan_ng<2, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 3: return hm_launch_scan_ng<3, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 4: return hm_launch_scan_ng<4, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 6: return hm_launch_scan_ng<6, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 8: return hm_launch_scan_ng<8, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 10: return hm_launch_scan_ng<10, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 13: return hm_launch_scan_ng<13, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 16: return hm_launch_scan_ng<16, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 20: return hm_launch_scan_ng<20, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 25: return hm_launch_scan_ng<25, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 28: return hm_launch_scan_ng<28, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
-        case 32: return hm_launch_scan_ng<32, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s);
+        case 1: return hm_launch_scan_ng<1, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 2: return hm_launch_scan_ng<2, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 3: return hm_launch_scan_ng<3, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 4: return hm_launch_scan_ng<4, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 6: return hm_launch_scan_ng<6, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 8: return hm_launch_scan_ng<8, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 10: return hm_launch_scan_ng<10, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 13: return hm_launch_scan_ng<13, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 16: return hm_launch_scan_ng<16, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 20: return hm_launch_scan_ng<20, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 25: return hm_launch_scan_ng<25, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 28: return hm_launch_scan_ng<28, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 32: return hm_launch_scan_ng<32, 0, HM_TM_F32, 4, 2>(e->sign_mode, mode, a, grid, s, ev0, ev1);
     }
     return hipErrorInvalidValue;
 }
@@ -1898,9 +1903,7 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
     }
     hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, e->d_ctr64, e->d_ctr, a.row_begin, a.row_end);
     HM_HIP(hipGetLastError());
-    HM_HIP(hipEventRecord(e->ev0, s));
-    HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s));
-    HM_HIP(hipEventRecord(e->ev1, s));
+    HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, e->ev0, e->ev1));
     hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(HM_ARGMIN_BLOCKS), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img, e->RS,
                        e->d, e->sign_mode, sqrtf(c), thr, e->d_parts);
     HM_HIP(hipGetLastError());
@@ -1936,9 +1939,7 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
         } else {
             HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
         }
-        HM_HIP(hipEventRecord(e->ev0, s));
-        HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s));
-        HM_HIP(hipEventRecord(e->ev1, s));
+        HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, e->ev0, e->ev1));
         hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(HM_ARGMIN_BLOCKS), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img,
                            e->RS, e->d, e->sign_mode, sqrt_c, thr, e->d_parts);
         HM_HIP(hipGetLastError());
@@ -2103,9 +2104,7 @@ static int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row
         a.tie_imax = tie_imax;
         HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
         HM_HIP(hipMemsetAsync(e->d_ctr64, 0, sizeof(unsigned long long) * 2, s));
-        HM_HIP(hipEventRecord(e->ev0, s));
-        HM_HIP(hm_launch_scan(e, HM_MODE_TOPK, a, grid, s));
-        HM_HIP(hipEventRecord(e->ev1, s));
+        HM_HIP(hm_launch_scan(e, HM_MODE_TOPK, a, grid, s, e->ev0, e->ev1));
         hipLaunchKernelGGL(hm_post_distance_kernel, dim3(512), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img, e->RS, e->d,
                            e->sign_mode, sqrt_c, thr, e->d_ctr + 1);
         HM_HIP(hipGetLastError());
