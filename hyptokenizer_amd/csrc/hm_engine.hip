@@ -1287,13 +1287,57 @@ __global__ __launch_bounds__(64) void hm_merge_append_kernel(float* __restrict__
         sy[k] = k == 0 ? hm_img_time(img, RS, rj) : hm_img_spatial(img, RS, rj, k - 1);
     }
     __syncthreads();
+    // Same operations, same order as hm_midpoint_core -- the element-wise steps spread over the wave, the three
+    // reductions (canonical order) and the scalar transcendental steps on lane 0.
+    __shared__ float sc[4];                      // coef, m, nn | ch, sh via sc[2], sc[3] after the second reduction
+    for (int k = lane; k < d; k += 64) so[k] = sx[1 + k] * sy[1 + k];              // products, rounded separately
+    __syncthreads();
     if (lane == 0) {
-        float r2 = 0.0f;
-        hm_midpoint_core(d, w, c, sign_mode, [&](int k) { return sx[k]; }, [&](int k) { return sy[k]; },
-                         [&](int k, float v) { so[k] = v; r2 = __builtin_fmaf(v, v, r2); }, sv);
-        if (r2 < 3.0e38f && r2 > 0.0f) {
-            atomicMax(rmax2_bits, hm::fbits(r2));
-            const float s2 = r2 - so[0] * so[0];
+        const float S = hm::torch_order_sum([&](int t) { return so[t]; }, d);
+        const float t0 = sx[0] * sy[0];
+        const float mref = t0 - S;
+        const float u = sign_mode ? mref : -mref;
+        const float a = hm::clamp_min_one(u);
+        float coef = hm::acosh_c(a) / __builtin_sqrtf(a * a - 1.0f);
+        if (coef == coef && coef > 1.0e4f) coef = 1.0e4f;
+        sc[0] = coef;
+        sc[1] = -u;
+    }
+    __syncthreads();
+    {
+        const float coef = sc[0], m = sc[1];
+        for (int k = lane; k <= d; k += 64) {
+            const float v = (coef * (sy[k] + m * sx[k])) * w;                      // w * log_map
+            sv[k] = v;
+            if (k >= 1) so[k - 1] = v * v;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float n2 = hm::torch_order_sum([&](int t) { return so[t]; }, d);
+        if (n2 == n2 && n2 < 1.0e-8f) n2 = 1.0e-8f;
+        const float nn = __builtin_sqrtf(n2);
+        sc[1] = nn;
+        sc[2] = hm::cosh_c(nn);
+        sc[3] = hm::sinh_c(nn);
+    }
+    __syncthreads();
+    {
+        const float nn = sc[1], ch = sc[2], sh = sc[3];
+        for (int k = 1 + lane; k <= d; k += 64) so[k] = ch * sx[k] + sh * (sv[k] / nn);   // exp_map, spatial part
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float r2 = 0.0f;                                                               // project: sequential fmaf chain
+        for (int k = 1; k <= d; ++k) r2 = __builtin_fmaf(so[k], so[k], r2);
+        const float rr = __builtin_sqrtf(r2);
+        const float x0 = __builtin_sqrtf(1.0f + (c * rr) * rr);
+        so[0] = x0;
+        float q2 = __builtin_fmaf(x0, x0, 0.0f);                                       // norm bounds of the new row
+        for (int k = 1; k <= d; ++k) q2 = __builtin_fmaf(so[k], so[k], q2);
+        if (q2 < 3.0e38f && q2 > 0.0f) {
+            atomicMax(rmax2_bits, hm::fbits(q2));
+            const float s2 = q2 - x0 * x0;
             if (s2 > 0.0f) atomicMax(rmax2_bits + 1, hm::fbits(s2 * 1.0001f));
         }
     }
