@@ -166,6 +166,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_WPB_BF16 4              // bf16 form: waves per block (all share each streamed 64-row tile)
 #endif
 #define HM_MAX_BLOCK_ROWS 512
+#define HM_MAX_D1 132              // largest table width (d + 1 <= 129) rounded up
 #define HM_COLS_PER_TILE 64        // partner rows per LDS tile
 #define HM_TIE_SLACK 1024u         // ulps of u' that are treated as "may still order before" (d is 2.5-ulp monotone)
 #define HM_MODE_TOPK 0
@@ -1007,6 +1008,7 @@ __device__ __forceinline__ bool hm_key_less(uint32_t a0, uint32_t a1, uint32_t a
 // canonical distance of every entry, threshold, lexicographic min of (dbits, i, j).
 // Stage 1: HM_ARGMIN_BLOCKS blocks, one partial record each; stage 2: one block over the partials.
 #define HM_ARGMIN_BLOCKS 256
+#define HM_POST_WAVE_ENTRIES 4096u   // up to this many emitted entries the argmin post kernel works one wave per entry
 struct ArgminPart { uint32_t dbits, i, j, pad; };
 
 __device__ __forceinline__ void hm_block_min_key(uint32_t& b0, uint32_t& b1, uint32_t& b2, uint32_t* s0, uint32_t* s1, uint32_t* s2)
@@ -1029,15 +1031,44 @@ __global__ __launch_bounds__(256) void hm_post_argmin_kernel(const uint4* __rest
                                                              int sign_mode, float sqrt_c, float thr, ArgminPart* __restrict__ parts)
 {
     __shared__ uint32_t s0[256], s1[256], s2[256];
+    __shared__ float sp[4][HM_MAX_D1];
     uint32_t m = ctr[0];
     if (m > cap) m = cap;
     uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
-    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < m; t += gridDim.x * 256) {
-        const uint4 en = ent[t];
-        const float dd = hm::dist_from_u(hm_img_u(img, RS, d, en.y, en.z, sign_mode), sqrt_c);
-        if (dd < thr) {
-            const uint32_t db = hm::fbits(dd);
-            if (hm_key_less(db, en.y, en.z, b0, b1, b2)) { b0 = db; b1 = en.y; b2 = en.z; }
+    if (m <= HM_POST_WAVE_ENTRIES) {
+        // the usual case (a few hundred survivors): one WAVE per entry -- the d products are formed by the lanes
+        // (coalesced row reads) and summed by lane 0 in the canonical order; the step waits on this kernel's latency
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (uint32_t t = blockIdx.x * 4 + wv; t < m; t += gridDim.x * 4) {
+            const uint4 en = ent[t];
+            const float* ra = img + (int64_t)en.y * RS;
+            const float* rb = img + (int64_t)en.z * RS;
+            for (int k = lane; k < d; k += 64) {
+                const int o = 4 * (k >> 2) + hm_pos_in_group(k & 3);
+                sp[wv][k] = ra[o] * rb[o];
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            if (lane == 0) {
+                const float S = hm::torch_order_sum([&](int q) { return sp[wv][q]; }, d);
+                const float tt = ra[RS - 4] * rb[RS - 4];
+                const float mm = tt - S;
+                const float dd = hm::dist_from_u(sign_mode ? mm : -mm, sqrt_c);
+                if (dd < thr) {
+                    const uint32_t db = hm::fbits(dd);
+                    if (hm_key_less(db, en.y, en.z, b0, b1, b2)) { b0 = db; b1 = en.y; b2 = en.z; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < m; t += gridDim.x * 256) {
+            const uint4 en = ent[t];
+            const float dd = hm::dist_from_u(hm_img_u(img, RS, d, en.y, en.z, sign_mode), sqrt_c);
+            if (dd < thr) {
+                const uint32_t db = hm::fbits(dd);
+                if (hm_key_less(db, en.y, en.z, b0, b1, b2)) { b0 = db; b1 = en.y; b2 = en.z; }
+            }
         }
     }
     hm_block_min_key(b0, b1, b2, s0, s1, s2);
@@ -1255,7 +1286,6 @@ __device__ __forceinline__ void hm_midpoint_core(int d, float w, float c, int si
     for (int k = 1; k <= d; ++k) put(k, scratch[k]);
 }
 
-#define HM_MAX_D1 132
 
 __global__ void hm_midpoint_kernel(const float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
                                    const int32_t* __restrict__ J, const float* __restrict__ W, int64_t b, float c,
