@@ -88,7 +88,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_MIN_WAVES 2             // __launch_bounds__ second argument (waves per SIMD): 2 blocks per CU
 #endif
 #ifndef HM_TM_F32
-#define HM_TM_F32 1                // fp32 form: 32-row MFMA tiles per wave (block = 128 rows, 2 blocks per CU)
+#define HM_TM_F32 2                // fp32 form: 64-row MFMA tiles per wave (block = 256 rows, 2 blocks per CU, 226 VGPRs)
 #endif
 // timing diagnostics only (wrong results): drop one ingredient of the bf16 scan loop
 #ifndef HM_DIAG_NO_DMA
