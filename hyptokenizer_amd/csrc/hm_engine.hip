@@ -140,6 +140,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef HM_SETTLE_PROLOGUE
 #define HM_SETTLE_PROLOGUE 1       // compiler-visible vmcnt(0) before the tile loop (keeps hipcc's lazy waits out of it)
 #endif
+#ifndef HM_DMA_GROUPED_F32
+#define HM_DMA_GROUPED_F32 1         // fp32 form: same grouped, unconditional LDS-DMA as the bf16 form (instead of one piece between MFMA groups)
+#endif
 #ifndef HM_DMA_GROUPED
 #define HM_DMA_GROUPED 1           // bf16 form: LDS-DMA pieces issued four per statement, unconditionally (see hm_dma_group)
 #endif
@@ -637,10 +640,11 @@ __global__ __launch_bounds__(64 * WPB, BF ? HM_MIN_WAVES_BF16 : HM_MIN_WAVES) vo
                      : "memory");
     };
     auto dma_tile = [&](int ct, int buf) {
-        if constexpr (BF && HM_DMA_GROUPED) {
+        if constexpr ((BF && HM_DMA_GROUPED) || (!BF && HM_DMA_GROUPED_F32)) {
             // bf16 form: wave w moves the PPW consecutive pieces [w * PPW, (w + 1) * PPW), four per statement
             if (HM_DIAG_NO_DMA) return;
-            const char* src = reinterpret_cast<const char*>(p.img16) + (int64_t)(HM_DIAG_SAME_TILES ? (ct & 7) : ct) * TILE_BYTES + lane * 16 + wave * (PPW * 1024);
+            const char* src = (BF ? reinterpret_cast<const char*>(p.img16) : reinterpret_cast<const char*>(p.img)) +
+                              (int64_t)(HM_DIAG_SAME_TILES ? (ct & 7) : ct) * TILE_BYTES + lane * 16 + wave * (PPW * 1024);
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * (uint32_t)TILE_LDS + (uint32_t)wave * (PPW * 1024u));
             hm_dma_run<PPW>(src, dst);
         } else {
@@ -673,8 +677,8 @@ __global__ __launch_bounds__(64 * WPB, BF ? HM_MIN_WAVES_BF16 : HM_MIN_WAVES) vo
     auto tile_at = [&](int t) { int q = t + rot; if (q >= ntile) q -= ntile; return ct0 + q * ct_step; };
 
     // ring prologue: tiles 0 .. DIST-1 in flight, tile 0 landed
-    constexpr bool ASYNC_KEY = (BF && HM_DMA_GROUPED) || DIST == 1;   // the running argmin key is re-read behind the ring's own wait
-    constexpr bool ALWAYS = BF && HM_DMA_GROUPED;    // the ring always holds DIST tiles in flight (a repeat of the last
+    constexpr bool ASYNC_KEY = (BF && HM_DMA_GROUPED) || (!BF && HM_DMA_GROUPED_F32) || DIST == 1;   // the running argmin key is re-read behind the ring's own wait
+    constexpr bool ALWAYS = (BF && HM_DMA_GROUPED) || (!BF && HM_DMA_GROUPED_F32);    // the ring always holds DIST tiles in flight (a repeat of the last
                                                       // tile goes into the free slot when the chunk runs out): no branches
 #pragma unroll
     for (int q = 0; q < DIST; ++q)
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(64 * WPB, BF ? HM_MIN_WAVES_BF16 : HM_MIN_WAVES) vo
 #if HM_DMA_INTERLEAVE
                     // next tile's LDS-DMA pieces are issued between the MFMAs of the first k-groups: their
                     // issue slots hide behind the 64-cycle matrix instructions
-                    if (NP - 1 >= PPW && g >= 1 && g - 1 < PPW && has_next) dma_piece(ct_next, buf_next, (g - 1) * WPB + wave);
+                    if (!ALWAYS && NP - 1 >= PPW && g >= 1 && g - 1 < PPW && has_next) dma_piece(ct_next, buf_next, (g - 1) * WPB + wave);
 #endif
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm) {
