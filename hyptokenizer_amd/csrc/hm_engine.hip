@@ -1215,12 +1215,17 @@ __global__ void hm_compact_valid_kernel(const uint4* __restrict__ ent, uint32_t 
     }
 }
 
-// exact rank of every key among m unique keys; rank < k is written to out[rank]
+// exact rank of every key among m unique keys; rank < k is written to out[rank].  HM_RANK_SPLIT lanes share one
+// key, each counting a residue class of the staged tile (the sort sits on the refresh's critical path and m is
+// only ~2 * cache_size: one thread per key would leave most of the chip idle).
+#define HM_RANK_SPLIT 8
 __global__ __launch_bounds__(256) void hm_rank_sort_kernel(const uint4* __restrict__ ent, uint32_t m, uint4* __restrict__ out,
                                                            uint32_t k)
 {
     __shared__ uint4 tile[1024];
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    constexpr uint32_t KEYS = 256 / HM_RANK_SPLIT;              // keys per block
+    const uint32_t part = threadIdx.x % HM_RANK_SPLIT;
+    const uint32_t t = blockIdx.x * KEYS + threadIdx.x / HM_RANK_SPLIT;
     uint4 me = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0);
     if (t < m) me = ent[t];
     uint32_t rank = 0;
@@ -1232,12 +1237,14 @@ __global__ __launch_bounds__(256) void hm_rank_sort_kernel(const uint4* __restri
         }
         __syncthreads();
         const uint32_t lim = (m - base) < 1024u ? (m - base) : 1024u;
-        for (uint32_t q = 0; q < lim; ++q) {
+        for (uint32_t q = part; q < lim; q += HM_RANK_SPLIT) {
             const uint4 o = tile[q];
             rank += hm_key_less(o.x, o.y, o.z, me.x, me.y, me.z) ? 1u : 0u;
         }
     }
-    if (t < m && rank < k) out[rank] = me;
+#pragma unroll
+    for (int off = 1; off < HM_RANK_SPLIT; off <<= 1) rank += __shfl_xor(rank, off, 64);
+    if (part == 0 && t < m && rank < k) out[rank] = me;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2089,7 +2096,7 @@ static int hm_select_sorted(hm_engine* e, uint4* src, uint4* other, uint32_t m, 
         mcur = e->h->ctr[3];
         if (mcur > 4u * HM_RANK_LIMIT) return hm_fail(e, HM_E_CAPACITY, "top-k: radix narrowing did not converge");
     }
-    hipLaunchKernelGGL(hm_rank_sort_kernel, dim3((mcur + 255) / 256), dim3(256), 0, s, cur, mcur, e->sorted, k);
+    hipLaunchKernelGGL(hm_rank_sort_kernel, dim3((mcur + 256 / HM_RANK_SPLIT - 1) / (256 / HM_RANK_SPLIT)), dim3(256), 0, s, cur, mcur, e->sorted, k);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
