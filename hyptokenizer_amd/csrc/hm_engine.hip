@@ -1012,6 +1012,7 @@ __device__ __forceinline__ bool hm_key_less(uint32_t a0, uint32_t a1, uint32_t a
 // canonical distance of every entry, threshold, lexicographic min of (dbits, i, j).
 // Stage 1: HM_ARGMIN_BLOCKS blocks, one partial record each; stage 2: one block over the partials.
 #define HM_ARGMIN_BLOCKS 256
+#define HM_POSTD_WAVE_ENTRIES 65536u  // ... and the top-k post kernel up to this many
 #define HM_POST_WAVE_ENTRIES 4096u   // up to this many emitted entries the argmin post kernel works one wave per entry
 struct ArgminPart { uint32_t dbits, i, j, pad; };
 
@@ -1134,18 +1135,49 @@ __global__ void hm_post_distance_kernel(uint4* __restrict__ ent, const uint32_t*
                                         const float* __restrict__ img, int RS, int d, int sign_mode, float sqrt_c, float thr,
                                         uint32_t* __restrict__ counts)
 {
+    __shared__ float sp[4][HM_MAX_D1];
     uint32_t m = ctr[0];
     if (m > cap) m = cap;
     uint32_t nv = 0, nb = 0, bad = 0;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
-        const uint4 en = ent[t];
-        const float uc = hm::clamp_min_one(hm_img_u(img, RS, d, en.y, en.z, sign_mode));
-        const float dd = hm::acosh_c(uc) / sqrt_c;
-        const bool valid = dd < thr;
-        nv += valid ? 1u : 0u;
-        nb += (valid && en.w == 0u) ? 1u : 0u;
-        bad += (!valid && en.w != 0u) ? 1u : 0u;
-        ent[t] = make_uint4(valid ? hm::fbits(dd) : 0xffffffffu, en.y, en.z, hm::fbits(uc));
+    if (m <= HM_POSTD_WAVE_ENTRIES && blockDim.x == 256) {
+        // the usual refresh (~2 * cache_size survivors): one wave per entry -- coalesced row reads, products by the
+        // lanes, canonical sum on lane 0 (a thread per entry reads two scattered rows with every lane)
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (uint32_t t = blockIdx.x * 4 + wv; t < m; t += gridDim.x * 4) {
+            const uint4 en = ent[t];
+            const float* ra = img + (int64_t)en.y * RS;
+            const float* rb = img + (int64_t)en.z * RS;
+            for (int k = lane; k < d; k += 64) {
+                const int o = 4 * (k >> 2) + hm_pos_in_group(k & 3);
+                sp[wv][k] = ra[o] * rb[o];
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            if (lane == 0) {
+                const float S = hm::torch_order_sum([&](int q) { return sp[wv][q]; }, d);
+                const float tt = ra[RS - 4] * rb[RS - 4];
+                const float mm = tt - S;
+                const float uc = hm::clamp_min_one(sign_mode ? mm : -mm);
+                const float dd = hm::acosh_c(uc) / sqrt_c;
+                const bool valid = dd < thr;
+                nv += valid ? 1u : 0u;
+                nb += (valid && en.w == 0u) ? 1u : 0u;
+                bad += (!valid && en.w != 0u) ? 1u : 0u;
+                ent[t] = make_uint4(valid ? hm::fbits(dd) : 0xffffffffu, en.y, en.z, hm::fbits(uc));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < m; t += gridDim.x * blockDim.x) {
+            const uint4 en = ent[t];
+            const float uc = hm::clamp_min_one(hm_img_u(img, RS, d, en.y, en.z, sign_mode));
+            const float dd = hm::acosh_c(uc) / sqrt_c;
+            const bool valid = dd < thr;
+            nv += valid ? 1u : 0u;
+            nb += (valid && en.w == 0u) ? 1u : 0u;
+            bad += (!valid && en.w != 0u) ? 1u : 0u;
+            ent[t] = make_uint4(valid ? hm::fbits(dd) : 0xffffffffu, en.y, en.z, hm::fbits(uc));
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
