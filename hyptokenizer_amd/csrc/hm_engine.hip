@@ -1541,7 +1541,7 @@ struct hm_engine {
     unsigned char* img16 = nullptr;       // bf16 image for the bf16 prefilter form
     int KS = 0, RB16 = 0;                 // k-steps of 16 and bytes per bf16 image row
     int precision = 0;                    // 0 = auto, 1 = fp32 prefilter, 2 = bf16 prefilter
-    bool bf16_ok = true;                  // auto mode: reserved for a norm-based veto of the bf16 form
+    bool bf16_ok = true;                  // false: no bf16 image for this width (d > 124); the fp32 form is used whatever is asked
     uint4* ent = nullptr;
     uint4* ent2 = nullptr;
     uint4* sorted = nullptr;
@@ -1639,6 +1639,10 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     e->sign_mode = sign_mode;
     e->rows_alloc = (max_rows + HM_MAX_BLOCK_ROWS - 1) / HM_MAX_BLOCK_ROWS * HM_MAX_BLOCK_ROWS + HM_MAX_BLOCK_ROWS;
     e->KS = hm_pick_ks(e->d);
+    if (e->KS < 0) {                     // d > 124: the k-steps instantiated do not hold d + 4 slots -- fp32 form only
+        e->KS = 0;                       // (the bf16 image degenerates to its [x0] chunk)
+        e->bf16_ok = false;
+    }
     e->RB16 = 32 * e->KS + 16;
     {
         const char* pe = getenv("HM_SCAN_PRECISION");          // "f32" | "bf16" | unset = auto
@@ -1824,6 +1828,7 @@ static hipError_t hm_launch_scan_ng(int sign, int mode, const ScanArgs& a, dim3 
 // already short) unless a norm-based veto is set.
 static bool hm_use_bf16(const hm_engine* e)
 {
+    if (!e->bf16_ok) return false;
     if (e->precision == 1) return false;
     if (e->precision == 2) return true;
     return e->d >= 24 && e->bf16_ok;

@@ -72,7 +72,8 @@ def test_topk_matches_oracle(oracle, n, d, scale, mode):
             assert np.array_equal(_bits(gd), _bits(od)), (thr, k)
 
 
-@pytest.mark.parametrize("n,d,scale", [(257, 10, 0.05), (1000, 10, 0.05), (1500, 100, 0.05), (2100, 50, 0.05)])
+@pytest.mark.parametrize("n,d,scale", [(257, 10, 0.05), (1000, 10, 0.05), (1500, 100, 0.05), (2100, 50, 0.05), (900, 124, 0.05),
+                                       (900, 128, 0.05), (600, 1, 0.3)])
 @pytest.mark.parametrize("mode", ["lorentz", "reference"])
 def test_argmin_matches_oracle(oracle, n, d, scale, mode):
     X = lorentz_table(n, d, seed=43, scale=scale).numpy()
