@@ -228,3 +228,37 @@ def test_argmin_seed_follows_table_edits(oracle, mode):
     if mode == "lorentz":
         assert got is not None and (got[1], got[2]) == (17, n) and got[0] == 0.0
     check(X4)
+
+
+@pytest.mark.parametrize("n", [2, 3, 31, 65])
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_tiny_tables(oracle, n, mode):
+    """tables smaller than one MFMA tile / one row block"""
+    d = 30
+    X = lorentz_table(n, d, seed=n, scale=0.05).numpy()
+    eng, _ = _engine(torch.from_numpy(X), mode)
+    for thr in (0.2, 50.0):
+        od, oi, oj, oc = oracle.pairwise_topk(X, n, 1.0, thr, MODES[mode], 64)
+        gd, gi, gj, gc = eng.topk(1.0, thr, 64)
+        assert gc == oc and np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(_bits(gd), _bits(od))
+        a = eng.argmin(1.0, thr)
+        assert (a is None) == (oc == 0)
+        if a:
+            assert (a[1], a[2]) == (int(oi[0]), int(oj[0])) and _bits([a[0]])[0] == _bits(od)[0]
+
+
+def test_all_rows_identical_lorentz(oracle):
+    """every pair at distance 0 in the non-degenerate sign mode: the zero-class tie flood orders by (i, j)"""
+    n, d = 2500, 30
+    row = lorentz_table(1, d, seed=3, scale=0.05)
+    X = row.repeat(n, 1).numpy()
+    eng, _ = _engine(torch.from_numpy(X), "lorentz")
+    a = eng.argmin(1.0, 0.5)
+    assert a == (0.0, 0, 1)
+    assert eng.argmin(1.0, 0.5) == (0.0, 0, 1)                   # seeded repeat
+    gd, gi, gj, gc = eng.topk(1.0, 0.5, 300)
+    assert gc == n * (n - 1) // 2 and np.all(gd == 0.0)
+    want = [(0, j) for j in range(1, 301)]
+    assert list(zip(gi.tolist(), gj.tolist())) == want
+    b = eng.argmin(1.0, 0.5, 1000, 2000)
+    assert b == (0.0, 1000, 1001)
