@@ -262,3 +262,18 @@ def test_all_rows_identical_lorentz(oracle):
     assert list(zip(gi.tolist(), gj.tolist())) == want
     b = eng.argmin(1.0, 0.5, 1000, 2000)
     assert b == (0.0, 1000, 1001)
+
+
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_unbounded_threshold(oracle, mode):
+    """a threshold beyond every distance (cosh overflows to inf): every pair is a candidate"""
+    n, d = 1800, 24
+    X = lorentz_table(n, d, seed=8, scale=0.05).numpy()
+    eng, _ = _engine(torch.from_numpy(X), mode)
+    for thr in (1.0e4, 3.0e38):
+        od, oi, oj, oc = oracle.pairwise_topk(X, n, 1.0, thr, MODES[mode], 700, fast=True)
+        gd, gi, gj, gc = eng.topk(1.0, thr, 700)
+        assert gc == oc == n * (n - 1) // 2
+        assert np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(_bits(gd), _bits(od))
+        a = eng.argmin(1.0, thr)
+        assert (a[1], a[2]) == (int(oi[0]), int(oj[0])) and _bits([a[0]])[0] == _bits(od)[0]
