@@ -121,6 +121,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef HM_EVENT_FLAGS
 #define HM_EVENT_FLAGS hipEventDisableSystemFence   // scan timing events: no system-scope fence around the launch
 #endif
+#ifndef HM_ARM_NEXT
+#define HM_ARM_NEXT 1              // an argmin search leaves counters + running key initialised for the next one of the same range
+#endif
 #ifndef HM_PERSIST
 #define HM_PERSIST 0               // experiment (off): bf16 form, one resident block per slot walks an equal share of the
                                    // tile sequence -- no launch tail, but measured 50 % slower than the chunked grid
@@ -1088,7 +1091,8 @@ __global__ __launch_bounds__(HM_ARGMIN_BLOCKS) void hm_post_argmin_final_kernel(
                                                                                 const uint32_t* __restrict__ ctr, uint32_t cap,
                                                                                 ArgminSeed* seed, const float* __restrict__ img, int RS, int d,
                                                                                 int sign_mode, int bf, int kterms,
-                                                                                const uint32_t* __restrict__ rmax2_bits, uint32_t* emitted_out)
+                                                                                const uint32_t* __restrict__ rmax2_bits, uint32_t* emitted_out,
+                                                                                uint32_t* arm_ctr, unsigned long long* arm_ctr64, int arm_rb, int arm_re)
 {
     __shared__ uint32_t s0[HM_ARGMIN_BLOCKS], s1[HM_ARGMIN_BLOCKS], s2[HM_ARGMIN_BLOCKS];
     uint32_t b0 = parts[threadIdx.x].dbits, b1 = parts[threadIdx.x].i, b2 = parts[threadIdx.x].j;
@@ -1105,6 +1109,15 @@ __global__ __launch_bounds__(HM_ARGMIN_BLOCKS) void hm_post_argmin_final_kernel(
             if (u <= 1.0f) key = (0x3f7fffffull << 32) | (unsigned long long)((b1 << 15) | (b2 >> 2));
             else key = ((unsigned long long)hm::fbits(u + hm_scan_delta(bf != 0, kterms, rmax2_bits)) << 32) | 0xffffffffull;
             seed->key = key; seed->i = b1; seed->valid = 1u;
+        }
+        // arm the next search over the same row range: counters cleared, running key = seed (what hm_seed_init_kernel
+        // would do at its start) -- the merge loop then goes from the merge kernel straight into the scan
+        if (arm_ctr != nullptr && found != 2u) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) arm_ctr[q] = 0u;
+            const bool use = seed != nullptr && seed->valid != 0u && (int)seed->i >= arm_rb && (int)seed->i < arm_re;
+            arm_ctr64[0] = ~0ull;
+            arm_ctr64[1] = use ? seed->key : ~0ull;
         }
     }
 }
@@ -1550,6 +1563,8 @@ struct hm_engine {
     uint32_t* d_rmax2 = nullptr;          // float bits: [0] largest squared row norm, [1] largest squared spatial norm
     unsigned long long* d_ctr64 = nullptr; // 2 x u64
     ArgminRec* d_rec = nullptr;
+    bool armed = false;                   // the last argmin search left counters + running key ready for a search of
+    int64_t armed_rb = 0, armed_re = 0;   // rows [armed_rb, armed_re) as requested (cleared by every other entry point that uses them)
     ArgminSeed* d_seed = nullptr;         // running-key seed of the next argmin search (device-resident state)
     ArgminPart* d_parts = nullptr;
     uint32_t* d_hist = nullptr;           // HM_DIGIT_BINS
@@ -1721,6 +1736,7 @@ static int hm_build_rows(hm_engine* e, const float* X, int64_t ld, int64_t r0, i
 
 extern "C" int hm_set_table(hm_engine* e, const float* X_dev, int64_t ld, int64_t n_rows, void* stream)
 {
+    if (e) e->armed = false;
     if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_set_table: engine is NULL");
     if (!X_dev || ld < e->d1 || n_rows < 0 || n_rows > e->max_rows)
         return hm_fail(e, HM_E_ARG, "hm_set_table: bad table pointer / ld / n_rows");
@@ -1741,6 +1757,7 @@ extern "C" int hm_set_table(hm_engine* e, const float* X_dev, int64_t ld, int64_
 
 extern "C" int hm_update_rows(hm_engine* e, const float* X_dev, int64_t ld, int64_t row_begin, int64_t row_end, void* stream)
 {
+    if (e) e->armed = false;
     if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_update_rows: engine is NULL");
     if (!X_dev || ld < e->d1 || row_begin < 0 || row_end < row_begin || row_end > e->max_rows)
         return hm_fail(e, HM_E_ARG, "hm_update_rows: bad arguments");
@@ -2011,6 +2028,7 @@ extern "C" int hm_debug_read_hist(hm_engine* e, uint32_t* out, int n)
 extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end, uint32_t* rec_dev,
                                       void* stream)
 {
+    if (e) e->armed = false;
     if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pairwise_argmin_dev: engine is NULL");
     if (!rec_dev) return hm_fail(e, HM_E_ARG, "hm_pairwise_argmin_dev: NULL record pointer");
     if (!(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pairwise_argmin_dev: curvature must be > 0");
@@ -2030,7 +2048,8 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
                        e->d, e->sign_mode, sqrtf(c), thr, e->d_parts);
     HM_HIP(hipGetLastError());
     hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts,
-                       reinterpret_cast<ArgminRec*>(rec_dev), e->d_ctr, e->ent_cap, HM_SEED_ARGS(e, a), (uint32_t*)nullptr);
+                       reinterpret_cast<ArgminRec*>(rec_dev), e->d_ctr, e->ent_cap, HM_SEED_ARGS(e, a), (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, (unsigned long long*)nullptr, 0, 0);
     HM_HIP(hipGetLastError());
     e->pending_timing = true;
     e->pending_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
@@ -2050,14 +2069,19 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
     e->last_scan_ms = 0.f; e->last_pairs = 0; e->last_emitted = 0; e->last_passes = 0;
     const Bounds b = hm_bounds(thr, c);
     ScanArgs a; dim3 grid;
+    const int64_t req_rb = row_begin, req_re = row_end;          // as asked (row_end < 0 = all rows): what "same range" means
+    const bool skip_init = HM_ARM_NEXT && e->armed && e->armed_rb == req_rb && e->armed_re == req_re;
+    e->armed = false;
     if (b.none || e->n < 2 || !hm_prepare_scan(e, b, row_begin, row_end, a, grid)) return HM_OK;
     const float sqrt_c = sqrtf(c);
     for (int pass = 0; pass < 2; ++pass) {
         // pass 1 (after an overflow) keeps the final running key of pass 0: every wave then starts
         // with the tight bound and only the band around the minimum is emitted
         if (pass == 0) {
-            hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, e->d_ctr64, e->d_ctr, a.row_begin, a.row_end);
-            HM_HIP(hipGetLastError());
+            if (!skip_init) {           // else: the previous search of this range left counters and key armed
+                hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, e->d_ctr64, e->d_ctr, a.row_begin, a.row_end);
+                HM_HIP(hipGetLastError());
+            }
         } else {
             HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
         }
@@ -2066,7 +2090,8 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
                            e->RS, e->d, e->sign_mode, sqrt_c, thr, e->d_parts);
         HM_HIP(hipGetLastError());
         hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec, e->d_ctr, e->ent_cap,
-                           HM_SEED_ARGS(e, a), reinterpret_cast<uint32_t*>(e->d_rec + 1));
+                           HM_SEED_ARGS(e, a), reinterpret_cast<uint32_t*>(e->d_rec + 1), e->d_ctr, e->d_ctr64,
+                           (int)std::max<int64_t>(req_rb, 0), req_re < 0 ? 0x7fffffff : (int)std::min<int64_t>(req_re, 0x7fffffff));
         HM_HIP(hipGetLastError());
         // record + emitted count (the slot behind the record) in one copy
         HM_HIP(hipMemcpyAsync(e->h->rec2, e->d_rec, 2 * sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
@@ -2088,6 +2113,7 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
         union { uint32_t u; float f; } cv; cv.u = e->h->rec.dbits;
         *found = 1; *d = cv.f; *i = (int32_t)e->h->rec.i; *j = (int32_t)e->h->rec.j;
     }
+    if (HM_ARM_NEXT && e->h->rec.found != 2u) { e->armed = true; e->armed_rb = req_rb; e->armed_re = req_re; }
     return HM_OK;
 }
 
@@ -2280,6 +2306,7 @@ static int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row
 extern "C" int hm_pairwise_topk(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, float* d_out,
                                 int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count, void* stream)
 {
+    if (e) e->armed = false;
     if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pairwise_topk: engine is NULL");
     if (!n_out || !count || k < 0 || (k > 0 && (!d_out || !i_out || !j_out)))
         return hm_fail(e, HM_E_ARG, "hm_pairwise_topk: bad output pointers / k");
@@ -2325,6 +2352,7 @@ extern "C" int hm_pairwise_topk(hm_engine* e, float c, float thr, int64_t k, int
 extern "C" int hm_pairwise_candidates(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end, int64_t cap,
                                       int32_t* i_out, int32_t* j_out, float* d_out, int64_t* total, void* stream)
 {
+    if (e) e->armed = false;
     if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pairwise_candidates: engine is NULL");
     if (!total || cap < 0 || (cap > 0 && (!i_out || !j_out || !d_out)))
         return hm_fail(e, HM_E_ARG, "hm_pairwise_candidates: bad output pointers");
@@ -2369,6 +2397,7 @@ extern "C" int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, floa
 extern "C" int hm_row_argmin(hm_engine* e, int64_t row, int64_t n_partners, float c, float thr, float* d, int32_t* i, int32_t* j,
                              int32_t* found, void* stream)
 {
+    if (e) e->armed = false;
     if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_row_argmin: engine is NULL");
     if (!d || !i || !j || !found) return hm_fail(e, HM_E_ARG, "hm_row_argmin: NULL output pointer");
     if (row < 0 || row >= e->n || n_partners < 0 || n_partners > e->n || !(c > 0.0f))
@@ -2382,7 +2411,8 @@ extern "C" int hm_row_argmin(hm_engine* e, int64_t row, int64_t n_partners, floa
                        n_partners, sqrtf(c), thr, e->d_parts);
     HM_HIP(hipGetLastError());
     hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts, e->d_rec, e->d_ctr, e->ent_cap,
-                       (ArgminSeed*)nullptr, e->img, e->RS, e->d, e->sign_mode, 0, e->RS, e->d_rmax2, (uint32_t*)nullptr);
+                       (ArgminSeed*)nullptr, e->img, e->RS, e->d, e->sign_mode, 0, e->RS, e->d_rmax2, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr, (unsigned long long*)nullptr, 0, 0);
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
     HM_HIP(hipStreamSynchronize(s));
@@ -2430,6 +2460,7 @@ extern "C" int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, floa
                        e->sign_mode, X_dev, ld, new_row, e->d_rmax2, e->img16, e->KS);
     HM_HIP(hipGetLastError());
     if (new_row < e->n) {
+        e->armed = false;
         e->have_cut = false;
         HM_HIP(hipMemsetAsync(e->d_seed, 0, sizeof(ArgminSeed), (hipStream_t)stream));
     }

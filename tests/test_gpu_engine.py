@@ -277,3 +277,37 @@ def test_unbounded_threshold(oracle, mode):
         assert np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(_bits(gd), _bits(od))
         a = eng.argmin(1.0, thr)
         assert (a[1], a[2]) == (int(oi[0]), int(oj[0])) and _bits([a[0]])[0] == _bits(od)[0]
+
+
+def test_armed_search_survives_interleaved_calls(oracle):
+    """an argmin search leaves the counters and the running key armed for the next search of the same range;
+    every other entry point that uses them must disarm"""
+    n, d = 3000, 30
+    X = lorentz_table(n, d, seed=17, scale=0.05).numpy()
+    eng, table = _engine(torch.from_numpy(X), "lorentz", max_rows=n + 64)
+    thr = 0.6
+    od, oi, oj, oc = oracle.pairwise_topk(X, n, 1.0, thr, 1, 1)
+    want = (float(od[0]), int(oi[0]), int(oj[0]))
+    assert eng.argmin(1.0, thr) == want
+    assert eng.argmin(1.0, thr) == want                           # armed
+    eng.row_argmin(5, 5, 1.0, thr)
+    assert eng.argmin(1.0, thr) == want
+    eng.topk(1.0, thr, 50)
+    assert eng.argmin(1.0, thr) == want
+    eng.candidates(1.0, 0.3)
+    assert eng.argmin(1.0, thr) == want
+    rec = torch.zeros(4, dtype=torch.int32, device="cuda")
+    eng.argmin_into(1.0, thr, 0, -1, rec)
+    torch.cuda.synchronize()
+    assert rec.tolist()[0] == 1 and tuple(rec.tolist()[2:]) == want[1:]
+    assert eng.argmin(1.0, thr) == want
+    assert eng.argmin(1.0, thr, 100, 2000) != want or want[1] >= 100   # another range: not armed for it
+    assert eng.argmin(1.0, thr) == want
+    assert eng.argmin(2.0, thr)[1:] == oracle_best(oracle, X, n, 2.0, thr)   # other curvature, same armed state
+    assert eng.argmin(1.0, 1e-6) is None                          # nothing below this threshold
+    assert eng.argmin(1.0, thr) == want
+
+
+def oracle_best(oracle, X, n, c, thr):
+    od, oi, oj, oc = oracle.pairwise_topk(X, n, c, thr, 1, 1)
+    return (int(oi[0]), int(oj[0]))
