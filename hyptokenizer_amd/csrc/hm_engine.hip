@@ -2028,7 +2028,6 @@ extern "C" int hm_debug_read_hist(hm_engine* e, uint32_t* out, int n)
 extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end, uint32_t* rec_dev,
                                       void* stream)
 {
-    if (e) e->armed = false;
     if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pairwise_argmin_dev: engine is NULL");
     if (!rec_dev) return hm_fail(e, HM_E_ARG, "hm_pairwise_argmin_dev: NULL record pointer");
     if (!(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pairwise_argmin_dev: curvature must be > 0");
@@ -2037,20 +2036,30 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
     hm_flush_pending_timing(e);
     const Bounds b = hm_bounds(thr, c);
     ScanArgs a; dim3 grid;
+    const int64_t req_rb = std::max<int64_t>(row_begin, 0), req_re = (row_end < 0 || row_end >= e->n) ? -1 : row_end;
+    const bool skip_init = HM_ARM_NEXT && e->armed && e->armed_rb == req_rb && e->armed_re == req_re;
+    e->armed = false;
     if (b.none || e->n < 2 || !hm_prepare_scan(e, b, row_begin, row_end, a, grid)) {
         HM_HIP(hipMemsetAsync(rec_dev, 0, sizeof(ArgminRec), s));        // found = 0
         return HM_OK;
     }
-    hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, e->d_ctr64, e->d_ctr, a.row_begin, a.row_end);
-    HM_HIP(hipGetLastError());
+    if (!skip_init) {
+        hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, e->d_ctr64, e->d_ctr, a.row_begin, a.row_end);
+        HM_HIP(hipGetLastError());
+    }
     HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, e->ev0, e->ev1));
     hipLaunchKernelGGL(hm_post_argmin_kernel, dim3(HM_ARGMIN_BLOCKS), dim3(256), 0, s, e->ent, e->d_ctr, e->ent_cap, e->img, e->RS,
                        e->d, e->sign_mode, sqrtf(c), thr, e->d_parts);
     HM_HIP(hipGetLastError());
     hipLaunchKernelGGL(hm_post_argmin_final_kernel, dim3(1), dim3(HM_ARGMIN_BLOCKS), 0, s, e->d_parts,
                        reinterpret_cast<ArgminRec*>(rec_dev), e->d_ctr, e->ent_cap, HM_SEED_ARGS(e, a), (uint32_t*)nullptr,
-                       (uint32_t*)nullptr, (unsigned long long*)nullptr, 0, 0);
+                       HM_ARM_NEXT ? e->d_ctr : (uint32_t*)nullptr, e->d_ctr64, (int)req_rb,
+                       req_re < 0 ? 0x7fffffff : (int)std::min<int64_t>(req_re, 0x7fffffff));
     HM_HIP(hipGetLastError());
+    // Armed optimistically: the host does not see this record.  Should the search have overflowed (found = 2, the
+    // kernel then arms nothing), the next search of this range starts on the stale counters, reports found = 2 as
+    // well, and its caller takes the bounded host path -- slower, never wrong.
+    if (HM_ARM_NEXT) { e->armed = true; e->armed_rb = req_rb; e->armed_re = req_re; }
     e->pending_timing = true;
     e->pending_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
     return HM_OK;
@@ -2069,7 +2078,8 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
     e->last_scan_ms = 0.f; e->last_pairs = 0; e->last_emitted = 0; e->last_passes = 0;
     const Bounds b = hm_bounds(thr, c);
     ScanArgs a; dim3 grid;
-    const int64_t req_rb = row_begin, req_re = row_end;          // as asked (row_end < 0 = all rows): what "same range" means
+    // the range as asked, "to the end" normalised (the table grows between searches): what "same range" means
+    const int64_t req_rb = std::max<int64_t>(row_begin, 0), req_re = (row_end < 0 || row_end >= e->n) ? -1 : row_end;
     const bool skip_init = HM_ARM_NEXT && e->armed && e->armed_rb == req_rb && e->armed_re == req_re;
     e->armed = false;
     if (b.none || e->n < 2 || !hm_prepare_scan(e, b, row_begin, row_end, a, grid)) return HM_OK;
