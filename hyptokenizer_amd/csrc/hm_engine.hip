@@ -598,6 +598,14 @@ __global__ __launch_bounds__(64 * WPB, BF ? HM_MIN_WAVES_BF16 : HM_MIN_WAVES) vo
     const float cut_f = cut_all ? p.u_hi : hm::bitsf(p.cut_bits) + delta;
 
 
+    // the running argmin key as it stands when the block starts (seeded, or found by earlier blocks): without it the
+    // block's first tile would run on the threshold bound alone -- with a threshold inside the bulk of the distance
+    // distribution that is thousands of emissions per block.  Waited for together with the fragment loads below.
+    if (MODE == HM_MODE_ARGMIN) {
+        const unsigned long long g0 = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g0 < gk) gk = g0;
+    }
+
     // ---- stationary A fragments: lane (r, h) keeps its operands of every k-step in registers ----
     float2 a[BF ? 1 : TM][BF ? 1 : NP];            // fp32 form: 2 operands (two k-steps) per group
     uint4 a16[BF ? TM : 1][BF ? NP : 1];           // bf16 form: 8 bf16 per 16-wide k-step
@@ -1563,6 +1571,8 @@ struct hm_engine {
     uint32_t* d_rmax2 = nullptr;          // float bits: [0] largest squared row norm, [1] largest squared spatial norm
     unsigned long long* d_ctr64 = nullptr; // 2 x u64
     ArgminRec* d_rec = nullptr;
+    float topk_f32_thr = 0.0f;            // > 0: top-k searches with a threshold at least this large needed the fp32 form on this table
+    bool force_f32 = false;               // set for the duration of one call: use the fp32 form whatever the default is
     bool armed = false;                   // the last argmin search left counters + running key ready for a search of
     int64_t armed_rb = 0, armed_re = 0;   // rows [armed_rb, armed_re) as requested (cleared by every other entry point that uses them)
     ArgminSeed* d_seed = nullptr;         // running-key seed of the next argmin search (device-resident state)
@@ -1751,6 +1761,7 @@ extern "C" int hm_set_table(hm_engine* e, const float* X_dev, int64_t ld, int64_
     if (rc) return rc;
     e->n = n_rows;
     e->have_cut = false;
+    e->topk_f32_thr = 0.0f;
     HM_HIP(hipMemsetAsync(e->d_seed, 0, sizeof(ArgminSeed), s));      // new table: no seed
     return HM_OK;
 }
@@ -1845,7 +1856,7 @@ static hipError_t hm_launch_scan_ng(int sign, int mode, const ScanArgs& a, dim3 
 // already short) unless a norm-based veto is set.
 static bool hm_use_bf16(const hm_engine* e)
 {
-    if (!e->bf16_ok) return false;
+    if (!e->bf16_ok || e->force_f32) return false;
     if (e->precision == 1) return false;
     if (e->precision == 2) return true;
     return e->d >= 24 && e->bf16_ok;
@@ -2117,7 +2128,15 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
         e->last_emitted = e->h->ctr[0];
         if (e->h->ctr[0] <= e->ent_cap) break;
         // overflow: the running key is the exact minimum over all published waves; rerun bounded by it
-        if (pass == 1) return hm_fail(e, HM_E_CAPACITY, "hm_pairwise_argmin: emission buffer overflow on the bounded pass");
+        if (pass == 1) {
+            if (a.bf16 && !e->force_f32) {      // the bf16 margin's shell around the bound is too populated: fp32 prefilter
+                e->force_f32 = true;
+                const int rc = hm_pairwise_argmin(e, c, thr, row_begin, row_end, d, i, j, found, stream);
+                e->force_f32 = false;
+                return rc;
+            }
+            return hm_fail(e, HM_E_CAPACITY, "hm_pairwise_argmin: emission buffer overflow on the bounded pass");
+        }
     }
     if (e->h->rec.found == 1u) {
         union { uint32_t u; float f; } cv; cv.u = e->h->rec.dbits;
@@ -2233,8 +2252,31 @@ static int hm_estimate_cut(hm_engine* e, ScanArgs a, dim3 grid, int64_t target, 
     return HM_OK;
 }
 
+static int hm_topk_core_form(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, bool list_all,
+                             int64_t* n_valid_emitted, int64_t* count, uint4** result_dev, hipStream_t s);
+
+// The bf16 prefilter's margin (delta ~ 0.004 * max||x_s||^2 in u) makes a shell of undecided pairs around the
+// threshold; every one of them has to be emitted to be decided exactly.  With a threshold inside the bulk of the
+// distance distribution that shell alone can exceed the emission buffer: the search then runs again with the fp32
+// prefilter, whose shell is ~100x thinner.
 static int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, bool list_all,
                         int64_t* n_valid_emitted, int64_t* count, uint4** result_dev, hipStream_t s)
+{
+    const bool had_bf16 = hm_use_bf16(e);
+    int rc = HM_E_CAPACITY;
+    if (!(had_bf16 && e->topk_f32_thr > 0.0f && thr >= e->topk_f32_thr))     // (a fallback is remembered per table)
+        rc = hm_topk_core_form(e, c, thr, k, row_begin, row_end, list_all, n_valid_emitted, count, result_dev, s);
+    if (rc == HM_E_CAPACITY && had_bf16) {
+        e->force_f32 = true;
+        rc = hm_topk_core_form(e, c, thr, k, row_begin, row_end, list_all, n_valid_emitted, count, result_dev, s);
+        e->force_f32 = false;
+        if (rc == HM_OK && !(e->topk_f32_thr > 0.0f && e->topk_f32_thr <= thr)) e->topk_f32_thr = thr;
+    }
+    return rc;
+}
+
+static int hm_topk_core_form(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, bool list_all,
+                             int64_t* n_valid_emitted, int64_t* count, uint4** result_dev, hipStream_t s)
 {
     *n_valid_emitted = 0;
     *count = 0;

@@ -311,3 +311,21 @@ def test_armed_search_survives_interleaved_calls(oracle):
 def oracle_best(oracle, X, n, c, thr):
     od, oi, oj, oc = oracle.pairwise_topk(X, n, c, thr, 1, 1)
     return (int(oi[0]), int(oj[0]))
+
+
+def test_threshold_inside_the_bulk_of_the_distances(oracle):
+    """half of all pairs are candidates: the bf16 prefilter's undecided shell around the threshold outgrows the
+    emission buffer and the search falls back to the fp32 prefilter; counts and lists stay exact"""
+    n, d = 9000, 50
+    X = lorentz_table(n, d, seed=12, scale=0.05).numpy()
+    eng, _ = _engine(torch.from_numpy(X), "lorentz")
+    s = eng.pair_distance(np.arange(0, 2000), np.arange(2000, 4000), 1.0)
+    thr = float(np.median(s))
+    od, oi, oj, oc = oracle.pairwise_topk(X, n, 1.0, thr, 1, 2000, fast=True)
+    assert oc > 0.3 * n * (n - 1) / 2
+    gd, gi, gj, gc = eng.topk(1.0, thr, 2000)
+    assert gc == oc and np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(_bits(gd), _bits(od))
+    for _ in range(2):
+        a = eng.argmin(1.0, thr)
+        assert (a[1], a[2]) == (int(oi[0]), int(oj[0])) and _bits([a[0]])[0] == _bits(od)[0]
+    assert eng.scan_stats()["emitted"] < 100000                   # seeded + key read at block start: no first-tile flood
