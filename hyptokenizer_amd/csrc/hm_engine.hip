@@ -2135,7 +2135,14 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
                 e->force_f32 = false;
                 return rc;
             }
-            return hm_fail(e, HM_E_CAPACITY, "hm_pairwise_argmin: emission buffer overflow on the bounded pass");
+            // Still too many pairs inside the running key's slack band (a very dense table: the band is 1024 ulps of
+            // u, which near u = 1 spans every distance below ~0.016): take the first entry of an exact top-1 search,
+            // whose emission cut is found by histogram zooming instead.
+            float d1 = 0.f; int32_t i1 = -1, j1 = -1; int64_t n1 = 0, cnt1 = 0;
+            const int rc = hm_pairwise_topk(e, c, thr, 1, row_begin, row_end, &d1, &i1, &j1, &n1, &cnt1, stream);
+            if (rc) return rc;
+            if (n1 > 0) { *found = 1; *d = d1; *i = i1; *j = j1; }
+            return HM_OK;
         }
     }
     if (e->h->rec.found == 1u) {

@@ -276,3 +276,23 @@ def test_device_record_and_world1_nccl_shard(oracle):
         assert torch.equal(runs[0][1].view(torch.int32), runs[1][1].view(torch.int32))      # bits: NaN rows included
     finally:
         dist.destroy_process_group()
+
+
+def test_very_dense_table_argmin_falls_back_to_exact_top1(oracle):
+    """131k points in a 2-D hyperboloid: tens of millions of pairs sit inside the running key's slack band, the
+    bounded second pass of the argmin search overflows too, and the search finishes through the top-1 path"""
+    from hyptokenizer_amd.engine import MergeEngine
+    V, d = 131064, 2
+    X = lorentz_table(V, d, seed=1, scale=0.05)
+    table = torch.zeros((V + 8, d + 1), device="cuda")
+    table[:V] = X.cuda()
+    eng = MergeEngine(V + 8, d + 1, "lorentz")
+    eng.set_table(table, V)
+    s = eng.pair_distance(np.arange(0, 3000), np.arange(3000, 6000), 1.0)
+    thr = float(np.percentile(s, 0.1))
+    od, oi, oj, oc = oracle.pairwise_topk(X.numpy(), V, 1.0, thr, 1, 200, fast=True)
+    a = eng.argmin(1.0, thr)
+    assert a is not None and (a[1], a[2]) == (int(oi[0]), int(oj[0])) and bits([a[0]])[0] == bits(od)[0]
+    assert eng.argmin(1.0, thr) == a
+    dd, ii, jj, cnt = eng.topk(1.0, thr, 200)
+    assert cnt == oc and np.array_equal(ii, oi) and np.array_equal(jj, oj) and np.array_equal(bits(dd), bits(od))
