@@ -67,11 +67,11 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_reproduce_the_single_process_run():
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_reproduce_the_single_process_run(world):
     os.environ["TQDM_DISABLE"] = "1"
     ref = _run(None)
     assert len(ref["std_merges"]) == 40 and len(ref["fast_merges"]) == 230 and ref["incr_merges"] == ref["std_merges"]
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
