@@ -45,6 +45,28 @@ for t in range(cases):
                 print("MISMATCH", dict(n=n, d=d, scale=scale, mode=mode, form=form, c=c, thr=thr, k=k, r0=r0, r1=r1, rep=rep), "gpu", cnt, a, "oracle", oc,
                       (float(od[0]), int(oi[0]), int(oj[0])) if oc else None, flush=True)
                 break
+        # merges: appended rows must carry the oracle's bits; the new row's nearest partner likewise
+        if n >= 4:
+            I = rng.integers(0, n, size=3).astype(np.int32); J = rng.integers(0, n, size=3).astype(np.int32)
+            W = rng.random(3).astype(np.float32)
+            want = O.midpoint_batch(Xn, I, J, W, c, sm)
+            for q in range(3):
+                eng.merge_append(int(I[q]), int(J[q]), float(W[q]), c, table, n + q)
+            got = table[n:n + 3].cpu().numpy()
+            if not np.array_equal(got.view(np.uint32), np.asarray(want, np.float32).view(np.uint32)):
+                bad += 1
+                print("MERGE MISMATCH", dict(n=n, d=d, scale=scale, mode=mode, c=c), flush=True)
+            full = np.concatenate([Xn, np.asarray(want, np.float32)], 0)
+            ra = eng.row_argmin(n + 2, n + 2, c, 1e30)
+            dist = np.asarray(O.row_vs_all(full, n + 3, n + 2, c, sm), np.float32)[:n + 2]
+            fin = np.nonzero(dist < np.float32(1e30))[0]
+            best = None
+            for q in fin.tolist():
+                key = (int(dist[q].view(np.uint32)), q)
+                best = key if best is None or key < best else best
+            if (ra is None) != (best is None) or (ra is not None and (int(np.float32(ra[0]).view(np.uint32)), ra[1]) != best):
+                bad += 1
+                print("ROW ARGMIN MISMATCH", dict(n=n, d=d, scale=scale, mode=mode, c=c), ra, best, flush=True)
     except Exception as ex:
         bad += 1
         print("ERROR", dict(n=n, d=d, scale=scale, mode=mode, form=form, c=c, thr=thr, k=k, r0=r0, r1=r1), repr(ex)[:200], flush=True)
