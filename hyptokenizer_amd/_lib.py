@@ -14,11 +14,15 @@ import os
 import torch  # noqa: F401  (side effect: loads torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhypmerge.so")
+# HYPMERGE_LIB: load another build of the same library (tools/ run kernel variants side by side); there is still no
+# fallback -- a path that does not load raises like the default one
+LIB_PATH = os.environ.get("HYPMERGE_LIB") or os.path.join(_HERE, "libhypmerge.so")
 
 HM_OK = 0
 HM_E_ARG, HM_E_CAPACITY, HM_E_STATE, HM_E_NOMEM = -1, -2, -3, -4
 SIGN_REFERENCE, SIGN_LORENTZ = 0, 1
+PREFILTER_AUTO, PREFILTER_F32, PREFILTER_BF16 = 0, 1, 2
+LOOP_MAX_STEPS = 64
 
 #: every symbol include/hypmerge.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = (
@@ -26,7 +30,9 @@ EXPORTED_SYMBOLS = (
     "hm_update_rows", "hm_rows", "hm_pairwise_argmin", "hm_pairwise_argmin_dev", "hm_pairwise_topk", "hm_pairwise_candidates",
     "hm_row_vs_all", "hm_row_argmin", "hm_pair_distance", "hm_midpoint_batch", "hm_merge_append", "hm_batch_distance",
     "hm_rows_minkowski", "hm_rows_distance", "hm_rows_log_map", "hm_rows_exp_map", "hm_rows_project",
-    "hm_last_scan_stats", "hm_scan_totals",
+    "hm_last_scan_stats", "hm_scan_totals", "hm_set_prefilter", "hm_pairwise_topk_nocount", "hm_pairwise_count",
+    "hm_merge_append_batch", "hm_truncate", "hm_set_token_lengths", "hm_std_merge_steps", "hm_incr_merge_steps",
+    "hm_coherence_batch", "hm_project_table", "hm_debug_force_cut",
 )
 
 
@@ -65,7 +71,18 @@ def load() -> C.CDLL:
     L.hm_abi_version.restype = C.c_int
     L.hm_last_error.restype = C.c_char_p
     L.hm_last_error.argtypes = [vp]
-    L.hm_engine_create.argtypes = [C.POINTER(vp), C.c_int, i64, C.c_int, C.c_int]
+    L.hm_engine_create.argtypes = [C.POINTER(vp), C.c_int, i64, C.c_int, C.c_int, C.c_int]
+    L.hm_set_prefilter.argtypes = [vp, C.c_int]
+    L.hm_pairwise_topk_nocount.argtypes = [vp, f32, f32, i64, i64, i64, vp, vp, vp, pi64, pi64, vp]
+    L.hm_pairwise_count.argtypes = [vp, f32, f32, i64, pi64, vp]
+    L.hm_merge_append_batch.argtypes = [vp, vp, vp, vp, i64, f32, vp, i64, i64, vp]
+    L.hm_truncate.argtypes = [vp, i64, vp]
+    L.hm_set_token_lengths.argtypes = [vp, vp, i64, vp]
+    L.hm_std_merge_steps.argtypes = [vp, f32, f32, vp, i64, i64, vp, pi64, vp]
+    L.hm_incr_merge_steps.argtypes = [vp, f32, f32, vp, i64, i64, vp, vp, pi64, vp]
+    L.hm_coherence_batch.argtypes = [vp, vp, vp, vp, vp, i64, C.c_int, f32, vp, vp]
+    L.hm_project_table.argtypes = [vp, vp, i64, i64, f32, vp]
+    L.hm_debug_force_cut.argtypes = [vp, C.c_uint32, i64, f32]
     L.hm_engine_destroy.argtypes = [vp]
     L.hm_set_table.argtypes = [vp, vp, i64, i64, vp]
     L.hm_update_rows.argtypes = [vp, vp, i64, i64, i64, vp]

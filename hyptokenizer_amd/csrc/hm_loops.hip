@@ -1,0 +1,268 @@
+// hm_loops.hip -- device-resident merge loops: several steps of HyperbolicTokenizer.optimize_merges
+// (tokenizer/hyperbolic_merge.py:357-412) per host call.
+//
+// What the host needs from a step is the pair (i, j) -- for the token strings -- and nothing else: the merge weight
+// len(tj) / (len(ti) + len(tj)) (hyperbolic_merge.py:317-323) only needs token LENGTHS, which live in a device array
+// here.  So K steps are enqueued back to back -- [pair scan -> tail kernel (exact re-evaluation, record, seed,
+// arming of the next scan, the merge itself)] x K, two launches per step, no host round trip in between -- and the
+// host reads the K records with ONE synchronisation.  A step that finds nothing (or overflows the emission buffer)
+// raises a stop word in HBM that turns every later launch of the batch into a no-op.
+//
+// The incremental form (rows are only ever appended, so the nearest pair is a running minimum) is ONE
+// launch per step: every block recomputes the merged row (cheaper than a grid-wide hand-off), block 0 stores it,
+// all blocks scan their slice of the image against it, and the last block to finish folds the new row's nearest
+// partner into the running minimum.
+#include "hm_common.h"
+#include "hm_rows_device.h"
+
+#pragma clang fp contract(off)
+
+extern "C" int hm_set_token_lengths(hm_engine* e, const int32_t* lens_host, int64_t n, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_set_token_lengths: engine is NULL");
+    if (!lens_host || n < 0 || n > e->max_rows) return hm_fail(e, HM_E_ARG, "hm_set_token_lengths: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (n) HM_HIP(hipMemcpyAsync(e->d_len, lens_host, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+    HM_HIP(hipStreamSynchronize(s));          // the caller's buffer is pageable: done with it on return
+    e->have_len = true;
+    return HM_OK;
+}
+
+// forget rows >= n_rows (a caller that appended rows ahead of time and changed its mind)
+extern "C" int hm_truncate(hm_engine* e, int64_t n_rows, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_truncate: engine is NULL");
+    if (n_rows < 0 || n_rows > e->n) return hm_fail(e, HM_E_ARG, "hm_truncate: n_rows outside [0, live rows]");
+    HM_HIP(hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (e->n > n_rows) {
+        HM_HIP(hipMemsetAsync(e->img + n_rows * e->RS, 0, sizeof(float) * (size_t)(e->n - n_rows) * e->RS, s));
+        HM_HIP(hipMemsetAsync(e->img16 + n_rows * e->RB16, 0, (size_t)(e->n - n_rows) * e->RB16, s));
+        e->armed = false;
+        e->have_cut = false;
+        HM_HIP(hipMemsetAsync(e->d_seed, 0, sizeof(ArgminSeed), s));
+    }
+    e->n = n_rows;
+    return HM_OK;
+}
+
+static void hm_unpack_recs(const ArgminRec* recs, int64_t steps, uint32_t* rec_out, int64_t* done)
+{
+    int64_t ok = 0;
+    bool counting = true;
+    for (int64_t k = 0; k < steps; ++k) {
+        rec_out[4 * k + 0] = recs[k].found; rec_out[4 * k + 1] = recs[k].dbits;
+        rec_out[4 * k + 2] = recs[k].i; rec_out[4 * k + 3] = recs[k].j;
+        if (counting && recs[k].found == 1u) ++ok; else counting = false;
+    }
+    *done = ok;
+}
+
+// K steps of the standard loop.  rec_out: steps x {found, bits(d), i, j}; *done = leading steps that merged.
+// A record with found = 0 ends the loop (no candidate), found = 2 asks the caller to run that step through
+// hm_pairwise_argmin + hm_merge_append (emission overflow), found = 3 marks steps skipped after either.
+extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev, int64_t ld, int64_t steps, uint32_t* rec_out,
+                                  int64_t* done, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_std_merge_steps: engine is NULL");
+    if (!X_dev || ld < e->d1 || !rec_out || !done || steps < 0 || steps > HM_LOOP_MAX_STEPS || !(c > 0.0f))
+        return hm_fail(e, HM_E_ARG, "hm_std_merge_steps: bad arguments");
+    if (!e->have_len) return hm_fail(e, HM_E_STATE, "hm_std_merge_steps: token lengths not set (hm_set_token_lengths)");
+    *done = 0;
+    if (steps == 0) return HM_OK;
+    if (e->n + steps > e->max_rows) return hm_fail(e, HM_E_CAPACITY, "hm_std_merge_steps: the table cannot take that many rows");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    hm_flush_pending_timing(e);
+    const Bounds b = hm_bounds(thr, c);
+    if (b.none || e->n < 2) {                 // nothing can be below the threshold
+        for (int64_t k = 0; k < steps; ++k) { rec_out[4 * k] = k == 0 ? 0u : 3u; rec_out[4 * k + 1] = 0; rec_out[4 * k + 2] = rec_out[4 * k + 3] = 0xffffffffu; }
+        return HM_OK;
+    }
+    const int64_t n0 = e->n;
+    const float sqrt_c = sqrtf(c);
+    HM_HIP(hipMemsetAsync(e->d_loop, 0, sizeof(LoopState), s));
+    bool armed = e->armed && e->armed_rb == 0 && e->armed_re == -1;
+    e->armed = false;
+    int64_t timed_pairs = 0;
+    for (int64_t k = 0; k < steps; ++k) {
+        ScanArgs a; dim3 grid;
+        if (!hm_prepare_scan(e, b, 0, -1, a, grid)) return hm_fail(e, HM_E_STATE, "hm_std_merge_steps: empty scan");
+        a.stop = &e->d_loop->stop;
+        if (!armed) {
+            int rc0 = hm_launch_seed_init(e, a, s);
+            if (rc0) { e->n = n0; return rc0; }
+        }
+        // the last scan of the batch carries the timing events (one event pair per engine)
+        const bool timed = (k == steps - 1);
+        HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, timed ? e->ev0 : nullptr, timed ? e->ev1 : nullptr));
+        if (timed) timed_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
+        MergeFuse mf;
+        mf.X = X_dev; mf.ld = ld; mf.new_row = e->n; mf.c = c;
+        mf.len = e->d_len; mf.len_rw = e->d_len; mf.loop = e->d_loop; mf.rec_ring = e->d_loop_recs + k;
+        int rc = hm_launch_argmin_tail(e, a, sqrt_c, thr, e->d_rec, true, 0, 0x7fffffff, true, mf, s);
+        if (rc) { e->n = n0; return rc; }
+        armed = true;
+        e->n += 1;                            // optimistic: corrected below when the batch stopped early
+    }
+    HM_HIP(hipMemcpyAsync(e->h->loop_recs, e->d_loop_recs, sizeof(ArgminRec) * (size_t)steps, hipMemcpyDeviceToHost, s));
+    HM_HIP(hipStreamSynchronize(s));
+    hm_unpack_recs(e->h->loop_recs, steps, rec_out, done);
+    e->n = n0 + *done;
+    e->armed = (*done == steps);
+    e->armed_rb = 0; e->armed_re = -1;
+    if (*done == steps) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) {
+            // one launch of the batch is timed; the totals count it once (bench: mean launch duration)
+            e->last_scan_ms = ms; e->last_pairs = timed_pairs; e->last_passes = 1;
+            e->tot_scan_ms += ms; e->tot_pairs += timed_pairs; e->tot_launches += 1;
+        }
+    }
+    return HM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// incremental loop
+// ------------------------------------------------------------------------------------------------
+struct IncrArgs {
+    float* img;
+    unsigned char* img16;
+    int RS, d, KS, sign_mode;
+    float c, sqrt_c, thr;
+    float* X;
+    int64_t ld;
+    int64_t new_row;             // = partners [0, new_row)
+    int32_t* len;
+    LoopState* loop;
+    ArgminPart* parts;
+    ArgminRec* rec_ring;         // this step's record
+    uint32_t* rmax2_bits;
+};
+
+__global__ __launch_bounds__(512) void hm_incr_step_kernel(const IncrArgs a)
+{
+    __shared__ uint32_t s0[8], s1[8], s2[8];
+    __shared__ uint32_t s_last;
+    __shared__ MidScratch ms;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    LoopState* loop = a.loop;
+    const uint32_t stop = loop->stop;
+    const ArgminRec best = loop->best;
+    if (stop != 0u || best.found != 1u) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ArgminRec r; r.found = stop != 0u ? 3u : 0u; r.dbits = 0; r.i = 0xffffffffu; r.j = 0xffffffffu;
+            *a.rec_ring = r;
+            if (stop == 0u) loop->stop = 1u;              // no pair below the threshold: the loop ends here
+        }
+        return;
+    }
+    // ---- the merged row: every block computes it (wave 0), block 0 stores it ----
+    if (wv == 0) {
+        const int32_t li = a.len[best.i], lj = a.len[best.j];
+        const float w = (float)((double)lj / (double)(li + lj));
+        hm_wave_stage_rows(a.img, a.RS, a.d, best.i, best.j, ms, lane);
+        const float r2 = hm_wave_midpoint(a.d, w, a.c, a.sign_mode, ms, true, lane);
+        if (blockIdx.x == 0) {
+            hm_wave_store_row(ms, r2, a.d, a.RS, a.KS, a.X, a.ld, a.img, a.img16, a.new_row, a.rmax2_bits, lane);
+            if (lane == 0) {
+                a.len[a.new_row] = li + lj;
+                *a.rec_ring = best;                        // the pair this step merged
+                loop->steps_done += 1u;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- nearest partner of the new row among rows [0, new_row): a half-wave per partner row ----
+    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
+    {
+        const int d = a.d, RS = a.RS;
+        const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+        const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 5;
+        const float x_time = ms.so[0];
+        for (int64_t i0 = hw & ~(int64_t)1; i0 < a.new_row; i0 += stride) {
+            int64_t i = i0 + (hw & 1);
+            const bool live = i < a.new_row;
+            if (!live) i = a.new_row - 1;
+            const float* ri = a.img + i * RS;
+            const float S = hm_halfwave_sum(d, lane, [&](int e) { return ri[hm_img_off(e)] * ms.so[1 + e]; });
+            const float tp = ri[RS - 4] * x_time;
+            const float mm = tp - S;
+            const float dd = hm::dist_from_u(a.sign_mode ? mm : -mm, a.sqrt_c);
+            if (live && dd < a.thr) {
+                const uint32_t db = hm::fbits(dd);
+                if (hm_key_less(db, (uint32_t)i, (uint32_t)a.new_row, b0, b1, b2)) { b0 = db; b1 = (uint32_t)i; b2 = (uint32_t)a.new_row; }
+            }
+        }
+    }
+    hm_block_min_key(b0, b1, b2, s0, s1, s2);
+    if (threadIdx.x == 0) {
+        ArgminPart pt; pt.dbits = b0; pt.i = b1; pt.j = b2; pt.pad = 0;
+        a.parts[blockIdx.x] = pt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t tk = __hip_atomic_fetch_add(&loop->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            loop->ticket = 0u;
+        }
+    }
+    __syncthreads();
+    if (s_last == 0u) return;
+    b0 = b1 = b2 = 0xffffffffu;
+    if (threadIdx.x < gridDim.x) {
+        const ArgminPart pt = a.parts[threadIdx.x];
+        b0 = pt.dbits; b1 = pt.i; b2 = pt.j;
+    }
+    hm_block_min_key(b0, b1, b2, s0, s1, s2);
+    if (threadIdx.x == 0) {
+        // running minimum: the pair just merged still exists (rows are never removed) and stays a candidate
+        ArgminRec nb = best;
+        if (b1 != 0xffffffffu && hm_key_less(b0, b1, b2, best.dbits, best.i, best.j)) { nb.dbits = b0; nb.i = b1; nb.j = b2; }
+        loop->best = nb;
+    }
+}
+
+// K steps of the incremental loop.  best_*: the current nearest pair (from a full search); on return the
+// running minimum after the last executed step.  rec_out / done as hm_std_merge_steps (found = 2 never occurs).
+extern "C" int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_dev, int64_t ld, int64_t steps, uint32_t* best_io,
+                                   uint32_t* rec_out, int64_t* done, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_incr_merge_steps: engine is NULL");
+    if (!X_dev || ld < e->d1 || !rec_out || !done || !best_io || steps < 0 || steps > HM_LOOP_MAX_STEPS || !(c > 0.0f))
+        return hm_fail(e, HM_E_ARG, "hm_incr_merge_steps: bad arguments");
+    if (!e->have_len) return hm_fail(e, HM_E_STATE, "hm_incr_merge_steps: token lengths not set (hm_set_token_lengths)");
+    *done = 0;
+    if (steps == 0) return HM_OK;
+    if (e->n + steps > e->max_rows) return hm_fail(e, HM_E_CAPACITY, "hm_incr_merge_steps: the table cannot take that many rows");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    e->armed = false;
+    const int64_t n0 = e->n;
+    LoopState st;
+    memset(&st, 0, sizeof(st));
+    st.best.found = best_io[0]; st.best.dbits = best_io[1]; st.best.i = best_io[2]; st.best.j = best_io[3];
+    memcpy(&e->h->rec2[0], &st.best, sizeof(ArgminRec));
+    HM_HIP(hipMemsetAsync(e->d_loop, 0, sizeof(LoopState), s));
+    HM_HIP(hipMemcpyAsync(&e->d_loop->best, &e->h->rec2[0], sizeof(ArgminRec), hipMemcpyHostToDevice, s));
+    IncrArgs a;
+    a.img = e->img; a.img16 = e->img16; a.RS = e->RS; a.d = e->d; a.KS = e->KS; a.sign_mode = e->sign_mode;
+    a.c = c; a.sqrt_c = sqrtf(c); a.thr = thr; a.X = X_dev; a.ld = ld; a.len = e->d_len; a.loop = e->d_loop;
+    a.parts = e->d_parts; a.rmax2_bits = e->d_rmax2;
+    for (int64_t k = 0; k < steps; ++k) {
+        a.new_row = n0 + k;
+        a.rec_ring = e->d_loop_recs + k;
+        hipLaunchKernelGGL(hm_incr_step_kernel, dim3(HM_ROWPASS_BLOCKS), dim3(512), 0, s, a);
+        HM_HIP(hipGetLastError());
+    }
+    HM_HIP(hipMemcpyAsync(e->h->loop_recs, e->d_loop_recs, sizeof(ArgminRec) * (size_t)steps, hipMemcpyDeviceToHost, s));
+    HM_HIP(hipMemcpyAsync(&e->h->rec, &e->d_loop->best, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
+    HM_HIP(hipStreamSynchronize(s));
+    hm_unpack_recs(e->h->loop_recs, steps, rec_out, done);
+    best_io[0] = e->h->rec.found; best_io[1] = e->h->rec.dbits; best_io[2] = e->h->rec.i; best_io[3] = e->h->rec.j;
+    e->n = n0 + *done;
+    return HM_OK;
+}

@@ -1,0 +1,538 @@
+// hm_rows.hip -- image construction, merge / midpoint, gathered and row-wise kernels, table re-projection and
+// the coherence kernel of the enhanced tokenizer, with their C-ABI entry points (include/hypmerge.h).
+//
+// All of these are bandwidth / latency kernels: rows are read coalesced (a half-wave reads
+// one 128-byte segment per instruction) and every canonical reduction is done wave-cooperatively
+// (hm_halfwave_sum: ATen's 32 chains, one per lane).
+#include "hm_common.h"
+#include "hm_rows_device.h"
+
+#pragma clang fp contract(off)
+
+// ------------------------------------------------------------------------------------------------
+// image construction
+// ------------------------------------------------------------------------------------------------
+__global__ void hm_build_image_kernel(const float* __restrict__ X, int64_t ld, int d, int NG, float* __restrict__ img,
+                                      int64_t row_begin, int64_t row_end)
+{
+    const int RS = hm_row_floats(NG);
+    const int64_t total = (row_end - row_begin) * RS;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = row_begin + t / RS;
+        const int p = (int)(t % RS);
+        const int g = p >> 2, q = p & 3;
+        float v = 0.0f;
+        if (g == RS / 4 - 1) {
+            if (q == 0) v = X[row * ld];
+        } else if (g < NG) {
+            const int s = 4 * g + (((q & 1) << 1) | (q >> 1));   // inverse of hm_pos_in_group
+            if (s < d) v = X[row * ld + 1 + s];
+        }
+        img[row * RS + p] = v;
+    }
+}
+
+// largest squared row norm [0] and largest squared spatial norm [1] of the live rows (finite rows
+// only), kept as float bits for atomicMax.  They scale the bound |u_f - u_c| used by the pair scan.
+__global__ void hm_rownorm_kernel(const float* __restrict__ img, int RS, int64_t row_begin, int64_t row_end,
+                                  uint32_t* __restrict__ rmax2_bits)
+{
+    const int64_t row = row_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float r2 = 0.0f, s2 = 0.0f;
+    if (row < row_end) {
+        const float* rr = img + row * RS;
+        for (int k = 0; k < RS - 4; ++k) s2 = __builtin_fmaf(rr[k], rr[k], s2);
+        r2 = __builtin_fmaf(rr[RS - 4], rr[RS - 4], s2);
+    }
+    if (!(r2 < 3.0e38f)) { r2 = 0.0f; s2 = 0.0f; }      // NaN / inf rows never form candidates
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        r2 = __builtin_fmaxf(r2, __shfl_xor(r2, off, 64));
+        s2 = __builtin_fmaxf(s2, __shfl_xor(s2, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (r2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(r2));
+        if (s2 > 0.0f) atomicMax(rmax2_bits + 1, hm::fbits(s2));
+    }
+}
+
+// bf16 image row: KS x 16 K-slots as bf16 (round to nearest even) followed by one 16-byte chunk
+// [x0 as fp32, 0, 0, 0] (2*KS + 1 chunks per row: always odd, so the ds_read_b128 fragment reads of
+// 32 consecutive rows fall on distinct 16-byte bank slots).
+__global__ void hm_build_image16_kernel(const float* __restrict__ X, int64_t ld, int d, int KS, unsigned char* __restrict__ img16,
+                                        int64_t row_begin, int64_t row_end)
+{
+    const int CH = 2 * KS + 1;                        // 16-byte chunks per row
+    const int64_t total = (row_end - row_begin) * CH;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = row_begin + t / CH;
+        const int c = (int)(t % CH);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const float* xr = X + row * ld;
+        if (c == CH - 1) v.x = hm::fbits(xr[0]);
+        else v = hm_bf16_chunk(xr + 1, xr[0], d, KS, c);
+        *reinterpret_cast<uint4*>(img16 + (row * CH + c) * 16) = v;
+    }
+}
+
+int hm_build_rows(hm_engine* e, const float* X, int64_t ld, int64_t r0, int64_t r1, hipStream_t s)
+{
+    if (r1 <= r0) return HM_OK;
+    const int64_t total = (r1 - r0) * e->RS;
+    int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(hm_build_image_kernel, dim3(blocks), dim3(256), 0, s, X, ld, e->d, e->NG, e->img, r0, r1);
+    HM_HIP(hipGetLastError());
+    hipLaunchKernelGGL(hm_rownorm_kernel, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, s, e->img, e->RS, r0, r1, e->d_rmax2);
+    HM_HIP(hipGetLastError());
+    const int64_t total16 = (r1 - r0) * (2 * e->KS + 1);
+    hipLaunchKernelGGL(hm_build_image16_kernel, dim3((unsigned)std::min<int64_t>((total16 + 255) / 256, 4096)), dim3(256), 0, s, X, ld,
+                       e->d, e->KS, e->img16, r0, r1);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gathered / one-vs-all distances on the image (half-wave per output, coalesced row reads)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hm_pairdist_kernel(const float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
+                                                          const int32_t* __restrict__ J, int64_t b, float sqrt_c, int sign_mode,
+                                                          float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;      // half-wave id = output index
+    const int64_t t = hw < b ? hw : b - 1;                                        // the wave's lanes stay together
+    const float u = hm_img_u_halfwave(img, RS, d, I[t], J[t], sign_mode, lane);
+    if (hw < b && (lane & 31) == 0) out[t] = hm::dist_from_u(u, sqrt_c);
+}
+
+__global__ __launch_bounds__(256) void hm_rowvsall_kernel(const float* __restrict__ img, int RS, int d, int64_t row, int64_t n,
+                                                          float sqrt_c, int sign_mode, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int64_t t = hw < n ? hw : n - 1;
+    const float u = hm_img_u_halfwave(img, RS, d, row, t, sign_mode, lane);
+    if (hw < n && (lane & 31) == 0) out[t] = hm::dist_from_u(u, sqrt_c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// midpoint / merge (one wave per pair)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hm_midpoint_kernel(const float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
+                                                          const int32_t* __restrict__ J, const float* __restrict__ W, int64_t b, float c,
+                                                          int sign_mode, float* __restrict__ out)
+{
+    __shared__ MidScratch ms[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wv;
+    if (t >= b) return;                                       // wave-uniform
+    hm_wave_stage_rows(img, RS, d, I[t], J[t], ms[wv], lane);
+    hm_wave_midpoint(d, W[t], c, sign_mode, ms[wv], true, lane);
+    for (int k = lane; k <= d; k += 64) out[t * (d + 1) + k] = ms[wv].so[k];
+}
+
+// fused merge: midpoint of image rows (i, j) -> table row and image rows `new_row` (hyperbolic_merge.py:326-351)
+__global__ __launch_bounds__(64) void hm_merge_append_kernel(float* __restrict__ img, int RS, int d, int32_t i, int32_t j, float w, float c,
+                                                             int sign_mode, float* __restrict__ X, int64_t ld, int64_t new_row,
+                                                             uint32_t* __restrict__ rmax2_bits, unsigned char* __restrict__ img16, int KS)
+{
+    __shared__ MidScratch ms;
+    const int lane = threadIdx.x;
+    hm_wave_stage_rows(img, RS, d, i, j, ms, lane);
+    const float r2 = hm_wave_midpoint(d, w, c, sign_mode, ms, true, lane);
+    hm_wave_store_row(ms, r2, d, RS, KS, X, ld, img, img16, new_row, rmax2_bits, lane);
+}
+
+// several merges known in advance (the fast tokenizer knows every merge between two refreshes when the refresh
+// returns): merge t reads rows (I[t], J[t]) -- which may be rows written by earlier merges of the same batch --
+// and writes row first_row + t.  One wave, sequential: the chain is a true dependency.
+__global__ __launch_bounds__(64) void hm_merge_batch_kernel(float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
+                                                            const int32_t* __restrict__ J, const float* __restrict__ W, int count, float c,
+                                                            int sign_mode, float* __restrict__ X, int64_t ld, int64_t first_row,
+                                                            uint32_t* __restrict__ rmax2_bits, unsigned char* __restrict__ img16, int KS)
+{
+    __shared__ MidScratch ms;
+    const int lane = threadIdx.x;
+    for (int t = 0; t < count; ++t) {
+        hm_wave_stage_rows(img, RS, d, I[t], J[t], ms, lane);
+        const float r2 = hm_wave_midpoint(d, W[t], c, sign_mode, ms, true, lane);
+        hm_wave_store_row(ms, r2, d, RS, KS, X, ld, img, img16, first_row + t, rmax2_bits, lane);
+        __threadfence();                                      // the next merge of the batch may read this row
+        hm_wave_lds_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// enhanced tokenizer (BASELINE config 5)
+// ------------------------------------------------------------------------------------------------
+// tokenizer/enhanced_fast_hyperbolic_merge.py:308-333 (_compute_semantic_coherence), one wave per candidate:
+// m = exp_map(x_i, w * log_map(x_i, x_j)) -- not projected -- kept in LDS, then distance(m, x_s) for the
+// candidate's ns sampled rows, a half-wave per sample.  out[t * ns + s].
+__global__ __launch_bounds__(256) void hm_coherence_kernel(const float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
+                                                           const int32_t* __restrict__ J, const float* __restrict__ W,
+                                                           const int32_t* __restrict__ S, int64_t b, int ns, float c, float sqrt_c,
+                                                           int sign_mode, float* __restrict__ out)
+{
+    __shared__ MidScratch ms[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5;
+    const int64_t t = (int64_t)blockIdx.x * 4 + wv;
+    if (t >= b) return;
+    MidScratch& m = ms[wv];
+    hm_wave_stage_rows(img, RS, d, I[t], J[t], m, lane);
+    hm_wave_midpoint(d, W[t], c, sign_mode, m, false, lane);
+    const float m0 = m.so[0];
+    for (int s0 = 0; s0 < ns; s0 += 2) {
+        const int s = s0 + h < ns ? s0 + h : ns - 1;          // both half-waves stay in the loop
+        const float* row = img + (int64_t)S[t * ns + s] * RS;
+        const float Ssum = hm_halfwave_sum(d, lane, [&](int e) { return m.so[1 + e] * row[hm_img_off(e)]; });
+        const float tp = m0 * row[RS - 4];
+        const float mm = tp - Ssum;
+        const float dd = hm::dist_from_u(sign_mode ? mm : -mm, sqrt_c);
+        if (s0 + h < ns && (lane & 31) == 0) out[t * ns + s] = dd;
+    }
+}
+
+// project_to_hyperboloid over rows [0, n_rows) of the caller's table in place (enhanced...:784-792): only
+// column 0 changes.  Rows below n_live also refresh the time slots of both images and the norm bounds.
+// 64 rows per block are staged through LDS with coalesced loads; a thread then runs its row's fmaf chain
+// (the canonical order of project is sequential) on LDS operands -- row stride d1 | 1: conflict-free.
+__global__ __launch_bounds__(64) void hm_project_table_kernel(float* __restrict__ X, int64_t ld, int d, int64_t n_rows, float c,
+                                                              float* __restrict__ img, int RS, unsigned char* __restrict__ img16, int KS,
+                                                              int64_t n_live, uint32_t* __restrict__ rmax2_bits)
+{
+    extern __shared__ float tile[];                           // 64 x stride
+    const int stride = d | 1;                                 // spatial part only, odd stride
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)(n_rows - r0 < 64 ? n_rows - r0 : 64);
+    const int lane = threadIdx.x;
+    for (int q = lane; q < rows * d; q += 64) {
+        const int r = q / d, k = q - r * d;
+        tile[r * stride + k] = X[(r0 + r) * ld + 1 + k];
+    }
+    __syncthreads();
+    float r2 = 0.0f, x0 = 0.0f;
+    if (lane < rows) {
+        const float* tr = tile + lane * stride;
+        for (int k = 0; k < d; ++k) r2 = __builtin_fmaf(tr[k], tr[k], r2);
+        const float rr = __builtin_sqrtf(r2);
+        x0 = __builtin_sqrtf(1.0f + (c * rr) * rr);
+        const int64_t row = r0 + lane;
+        X[row * ld] = x0;
+        if (row < n_live) {
+            img[row * RS + RS - 4] = x0;
+            const int CH = 2 * KS + 1;
+            unsigned char* r16 = img16 + row * CH * 16;
+            *reinterpret_cast<uint32_t*>(r16 + (CH - 1) * 16) = hm::fbits(x0);
+            if (KS > 0) {
+                const __bf16 hb = (__bf16)x0;
+                const float hi = (float)hb, lo = x0 - hi;
+                uint32_t* slots = reinterpret_cast<uint32_t*>(r16 + (2 * KS - 1) * 16 + 8);   // K-slots 8c+4 .. 8c+7 of the last chunk
+                slots[0] = hm_pack_bf16(hi, lo);
+                slots[1] = hm_pack_bf16(hi, 0.0f);
+            }
+        } else {
+            r2 = 0.0f; x0 = 0.0f;
+        }
+    }
+    float q2 = __builtin_fmaf(x0, x0, r2);
+    if (!(q2 < 3.0e38f)) { q2 = 0.0f; r2 = 0.0f; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        q2 = __builtin_fmaxf(q2, __shfl_xor(q2, off, 64));
+        r2 = __builtin_fmaxf(r2, __shfl_xor(r2, off, 64));
+    }
+    if (lane == 0) {
+        if (q2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(q2 * 1.0001f));
+        if (r2 > 0.0f) atomicMax(rmax2_bits + 1, hm::fbits(r2 * 1.0001f));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine-independent kernels on row-major arrays (embedding/lorentz_model.py function surface)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hm_rm_u(const float* x, const float* y, int d1, int sign_mode)
+{
+    const float S = hm::torch_order_sum([&](int s) { return x[1 + s] * y[1 + s]; }, d1 - 1);
+    const float t = x[0] * y[0];
+    const float m = t - S;
+    return sign_mode ? m : -m;
+}
+
+// half-wave per row pair (coalesced)
+__device__ __forceinline__ float hm_rm_u_halfwave(const float* x, const float* y, int d1, int sign_mode, int lane)
+{
+    const float S = hm_halfwave_sum(d1 - 1, lane, [&](int e) { return x[1 + e] * y[1 + e]; });
+    const float t = x[0] * y[0];
+    const float m = t - S;
+    return sign_mode ? m : -m;
+}
+
+// out[i, j] for a 2 x 32 tile of outputs per wave: half-wave h takes row i = 2 * blockIdx.y' + h ... kept simple:
+// one half-wave per output, outputs enumerated row-major
+__global__ __launch_bounds__(256) void hm_dense_kernel(const float* __restrict__ X, int64_t n1, const float* __restrict__ Y, int64_t n2,
+                                                       int64_t ldx, int64_t ldy, int d1, float sqrt_c, int sign_mode,
+                                                       float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t total = n1 * n2;
+    const int64_t hw0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int64_t step = ((int64_t)gridDim.x * blockDim.x) >> 5;
+    const int64_t rounds = (total + step - 1) / step;
+    for (int64_t r = 0; r < rounds; ++r) {
+        const int64_t o = hw0 + r * step;
+        const int64_t t = o < total ? o : total - 1;
+        const int64_t i = t / n2, j = t - i * n2;
+        const float u = hm_rm_u_halfwave(X + i * ldx, Y + j * ldy, d1, sign_mode, lane);
+        if (o < total && (lane & 31) == 0) out[t] = hm::dist_from_u(u, sqrt_c);
+    }
+}
+
+__global__ void hm_rows_minkowski_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t b, int64_t ld, int d1,
+                                         int sign_mode, float* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    // minkowski_dot under the active convention = -u
+    out[t] = -hm_rm_u(x + t * ld, y + t * ld, d1, sign_mode);
+}
+
+__global__ __launch_bounds__(256) void hm_rows_distance_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t b, int64_t ld,
+                                                               int d1, float sqrt_c, int sign_mode, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int64_t t = hw < b ? hw : b - 1;
+    const float u = hm_rm_u_halfwave(x + t * ld, y + t * ld, d1, sign_mode, lane);
+    if (hw < b && (lane & 31) == 0) out[t] = hm::dist_from_u(u, sqrt_c);
+}
+
+__global__ void hm_rows_log_map_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t b, int64_t ld, int d1,
+                                       int sign_mode, float* __restrict__ out, int64_t ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    const float* xr = x + t * ld;
+    const float* yr = y + t * ld;
+    const float u = hm_rm_u(xr, yr, d1, sign_mode);
+    const float m = -u;
+    const float a = hm::clamp_min_one(u);
+    float coef = hm::acosh_c(a) / __builtin_sqrtf(a * a - 1.0f);
+    if (coef == coef && coef > 1.0e4f) coef = 1.0e4f;
+    for (int k = 0; k < d1; ++k) out[t * ldo + k] = coef * (yr[k] + m * xr[k]);
+}
+
+__global__ void hm_rows_exp_map_kernel(const float* __restrict__ x, const float* __restrict__ v, int64_t b, int64_t ld, int d1,
+                                       float* __restrict__ out, int64_t ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    const float* xr = x + t * ld;
+    const float* vr = v + t * ld;
+    float n2 = hm::torch_order_sum([&](int s) { return vr[1 + s] * vr[1 + s]; }, d1 - 1);
+    if (n2 == n2 && n2 < 1.0e-8f) n2 = 1.0e-8f;
+    const float nn = __builtin_sqrtf(n2);
+    const float ch = hm::cosh_c(nn), sh = hm::sinh_c(nn);
+    for (int k = 0; k < d1; ++k) out[t * ldo + k] = ch * xr[k] + sh * (vr[k] / nn);
+}
+
+__global__ void hm_rows_project_kernel(const float* __restrict__ x, int64_t b, int64_t ld, int d1, float c, float* __restrict__ out,
+                                       int64_t ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    const float* xr = x + t * ld;
+    float r2 = 0.0f;
+    for (int k = 1; k < d1; ++k) r2 = __builtin_fmaf(xr[k], xr[k], r2);
+    const float rr = __builtin_sqrtf(r2);
+    const float x0 = __builtin_sqrtf(1.0f + (c * rr) * rr);
+    for (int k = 1; k < d1; ++k) out[t * ldo + k] = xr[k];
+    out[t * ldo] = x0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, float* d_out_dev, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_row_vs_all: engine is NULL");
+    if (!d_out_dev || row < 0 || row >= e->n || n < 0 || n > e->n || !(c > 0.0f))
+        return hm_fail(e, HM_E_ARG, "hm_row_vs_all: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    if (n == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+                       row, n, sqrtf(c), e->sign_mode, d_out_dev);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_pair_distance(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, int64_t b, float c, float* out_dev,
+                                void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pair_distance: engine is NULL");
+    if (b < 0 || (b > 0 && (!I_dev || !J_dev || !out_dev)) || !(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pair_distance: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_pairdist_kernel, dim3((unsigned)((b + 7) / 8)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+                       I_dev, J_dev, b, sqrtf(c), e->sign_mode, out_dev);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_midpoint_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev, int64_t b, float c,
+                                 float* out_dev, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_midpoint_batch: engine is NULL");
+    if (b < 0 || (b > 0 && (!I_dev || !J_dev || !W_dev || !out_dev))) return hm_fail(e, HM_E_ARG, "hm_midpoint_batch: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_midpoint_kernel, dim3((unsigned)((b + 3) / 4)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+                       I_dev, J_dev, W_dev, b, c, e->sign_mode, out_dev);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+static void hm_rows_changed(hm_engine* e, int64_t first_changed_row, hipStream_t s)
+{
+    if (first_changed_row < e->n) {          // an existing row changed: cut prediction, argmin seed and arming are void
+        e->armed = false;
+        e->have_cut = false;
+        (void)hipMemsetAsync(e->d_seed, 0, sizeof(ArgminSeed), s);
+    }
+}
+
+extern "C" int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, float c, float* X_dev, int64_t ld, int64_t new_row,
+                               void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_merge_append: engine is NULL");
+    if (!X_dev || ld < e->d1 || i < 0 || j < 0 || i >= e->n || j >= e->n || new_row < 0 || new_row >= e->max_rows)
+        return hm_fail(e, HM_E_ARG, "hm_merge_append: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    hipLaunchKernelGGL(hm_merge_append_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d, i, j, w, c,
+                       e->sign_mode, X_dev, ld, new_row, e->d_rmax2, e->img16, e->KS);
+    HM_HIP(hipGetLastError());
+    hm_rows_changed(e, new_row, (hipStream_t)stream);
+    if (new_row + 1 > e->n) e->n = new_row + 1;
+    return HM_OK;
+}
+
+extern "C" int hm_merge_append_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev, int64_t count,
+                                     float c, float* X_dev, int64_t ld, int64_t first_row, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_merge_append_batch: engine is NULL");
+    if (count < 0 || (count > 0 && (!I_dev || !J_dev || !W_dev || !X_dev)) || ld < e->d1 || first_row < 0 ||
+        first_row + count > e->max_rows || count > 1 << 20)
+        return hm_fail(e, HM_E_ARG, "hm_merge_append_batch: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    if (count == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_merge_batch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d, I_dev, J_dev, W_dev,
+                       (int)count, c, e->sign_mode, X_dev, ld, first_row, e->d_rmax2, e->img16, e->KS);
+    HM_HIP(hipGetLastError());
+    hm_rows_changed(e, first_row, (hipStream_t)stream);
+    if (first_row + count > e->n) e->n = first_row + count;
+    return HM_OK;
+}
+
+extern "C" int hm_coherence_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev, const int32_t* S_dev,
+                                  int64_t b, int ns, float c, float* out_dev, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_coherence_batch: engine is NULL");
+    if (b < 0 || ns < 0 || !(c > 0.0f) || (b > 0 && ns > 0 && (!I_dev || !J_dev || !W_dev || !S_dev || !out_dev)))
+        return hm_fail(e, HM_E_ARG, "hm_coherence_batch: bad arguments");
+    HM_HIP(hipSetDevice(e->device));
+    if (b == 0 || ns == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_coherence_kernel, dim3((unsigned)((b + 3) / 4)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+                       I_dev, J_dev, W_dev, S_dev, b, ns, c, sqrtf(c), e->sign_mode, out_dev);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_project_table(hm_engine* e, float* X_dev, int64_t ld, int64_t n_rows, float c, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_project_table: engine is NULL");
+    if (!X_dev || ld < e->d1 || n_rows < 0 || n_rows < e->n || !(c > 0.0f))
+        return hm_fail(e, HM_E_ARG, "hm_project_table: bad arguments (n_rows must cover the live rows)");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    if (n_rows == 0) return HM_OK;
+    HM_HIP(hipMemsetAsync(e->d_rmax2, 0, sizeof(uint32_t) * 2, s));
+    const size_t lds = sizeof(float) * 64 * (size_t)(e->d | 1);
+    hipLaunchKernelGGL(hm_project_table_kernel, dim3((unsigned)((n_rows + 63) / 64)), dim3(64), lds, s, X_dev, ld, e->d, n_rows, c,
+                       e->img, e->RS, e->img16, e->KS, e->n, e->d_rmax2);
+    HM_HIP(hipGetLastError());
+    // every live row changed
+    e->armed = false;
+    e->have_cut = false;
+    e->topk_f32_thr = 0.0f;
+    HM_HIP(hipMemsetAsync(e->d_seed, 0, sizeof(ArgminSeed), s));
+    return HM_OK;
+}
+
+// ---- engine-independent entry points ----
+extern "C" int hm_batch_distance(const float* X_dev, int64_t n1, const float* Y_dev, int64_t n2, int64_t ld_x, int64_t ld_y, int d1,
+                                 float c, int sign_mode, float* out_dev, void* stream)
+{
+    if (n1 < 0 || n2 < 0 || d1 < 2 || ld_x < d1 || ld_y < d1 || !(c > 0.0f)) return hm_fail(nullptr, HM_E_ARG, "hm_batch_distance: bad arguments");
+    if (n1 == 0 || n2 == 0) return HM_OK;
+    if (!X_dev || !Y_dev || !out_dev) return hm_fail(nullptr, HM_E_ARG, "hm_batch_distance: NULL pointer");
+    const int64_t total = n1 * n2;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 7) / 8, 8192);
+    hipLaunchKernelGGL(hm_dense_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X_dev, n1, Y_dev, n2, ld_x, ld_y, d1,
+                       sqrtf(c), sign_mode, out_dev);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_rows_minkowski(const float* x_dev, const float* y_dev, int64_t b, int64_t ld, int d1, int sign_mode, float* out_dev,
+                                 void* stream)
+{
+    if (b < 0 || d1 < 2 || ld < d1) return hm_fail(nullptr, HM_E_ARG, "hm_rows_minkowski: bad arguments");
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rows_minkowski_kernel, dim3((unsigned)((b + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x_dev, y_dev, b,
+                       ld, d1, sign_mode, out_dev);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_rows_distance(const float* x_dev, const float* y_dev, int64_t b, int64_t ld, int d1, float c, int sign_mode,
+                                float* out_dev, void* stream)
+{
+    if (b < 0 || d1 < 2 || ld < d1 || !(c > 0.0f)) return hm_fail(nullptr, HM_E_ARG, "hm_rows_distance: bad arguments");
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rows_distance_kernel, dim3((unsigned)((b + 7) / 8)), dim3(256), 0, (hipStream_t)stream, x_dev, y_dev, b,
+                       ld, d1, sqrtf(c), sign_mode, out_dev);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_rows_log_map(const float* x_dev, const float* y_dev, int64_t b, int64_t ld, int d1, int sign_mode, float* out_dev,
+                               int64_t ld_out, void* stream)
+{
+    if (b < 0 || d1 < 2 || ld < d1 || ld_out < d1) return hm_fail(nullptr, HM_E_ARG, "hm_rows_log_map: bad arguments");
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rows_log_map_kernel, dim3((unsigned)((b + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x_dev, y_dev, b,
+                       ld, d1, sign_mode, out_dev, ld_out);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_rows_exp_map(const float* x_dev, const float* v_dev, int64_t b, int64_t ld, int d1, float* out_dev, int64_t ld_out,
+                               void* stream)
+{
+    if (b < 0 || d1 < 2 || ld < d1 || ld_out < d1) return hm_fail(nullptr, HM_E_ARG, "hm_rows_exp_map: bad arguments");
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rows_exp_map_kernel, dim3((unsigned)((b + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x_dev, v_dev, b,
+                       ld, d1, out_dev, ld_out);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}
+
+extern "C" int hm_rows_project(const float* x_dev, int64_t b, int64_t ld, int d1, float c, float* out_dev, int64_t ld_out,
+                               void* stream)
+{
+    if (b < 0 || d1 < 2 || ld < d1 || ld_out < d1) return hm_fail(nullptr, HM_E_ARG, "hm_rows_project: bad arguments");
+    if (b == 0) return HM_OK;
+    hipLaunchKernelGGL(hm_rows_project_kernel, dim3((unsigned)((b + 127) / 128)), dim3(128), 0, (hipStream_t)stream, x_dev, b, ld, d1,
+                       c, out_dev, ld_out);
+    HM_HIP0(hipGetLastError());
+    return HM_OK;
+}

@@ -1,0 +1,94 @@
+// hm_rows_device.h -- wave-cooperative midpoint / merge (device code shared by hm_rows.hip, hm_search.hip and
+// hm_loops.hip).  Reference arithmetic: tokenizer/hyperbolic_merge.py:326-340 (log_map -> scale -> exp_map ->
+// project), embedding/lorentz_model.py:41-56,73-119.
+#pragma once
+#include "hm_common.h"
+
+// LDS scratch of one wave: the two operand rows, the scaled tangent and the result, in the reference's column
+// order (column 0 = time).
+struct MidScratch { float sx[HM_MAX_D1], sy[HM_MAX_D1], sv[HM_MAX_D1], so[HM_MAX_D1]; };
+
+__device__ __forceinline__ void hm_wave_lds_sync()
+{
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+}
+
+// stage image rows ri, rj into ms.sx / ms.sy (coalesced)
+__device__ __forceinline__ void hm_wave_stage_rows(const float* img, int RS, int d, int64_t ri, int64_t rj, MidScratch& ms, int lane)
+{
+    for (int k = lane; k <= d; k += 64) {
+        ms.sx[k] = k == 0 ? hm_img_time(img, RS, ri) : hm_img_spatial(img, RS, ri, k - 1);
+        ms.sy[k] = k == 0 ? hm_img_time(img, RS, rj) : hm_img_spatial(img, RS, rj, k - 1);
+    }
+    hm_wave_lds_sync();
+}
+
+// One wave: ms.so[0..d] = exp_map(x, w * log_map(x, y)), projected onto the hyperboloid when `project`.
+// Same operations in the same order as the one-lane form (hm_midpoint_core of round 1 / oracle hmo_midpoint):
+// element-wise steps spread over the lanes, the two torch-order reductions by hm_halfwave_sum (both half-waves
+// compute them redundantly), the scalar transcendental steps on every lane (uniform).  Returns the squared
+// spatial norm of the result (fmaf chain; only meaningful when `project`).
+__device__ __forceinline__ float hm_wave_midpoint(int d, float w, float c, int sign_mode, MidScratch& ms, bool project, int lane)
+{
+    // log_map (embedding/lorentz_model.py:96-119)
+    const float S = hm_halfwave_sum(d, lane, [&](int e) { return ms.sx[1 + e] * ms.sy[1 + e]; });
+    const float t0 = ms.sx[0] * ms.sy[0];
+    const float mref = t0 - S;
+    const float u = sign_mode ? mref : -mref;
+    const float m = -u;
+    const float a = hm::clamp_min_one(u);
+    float coef = hm::acosh_c(a) / __builtin_sqrtf(a * a - 1.0f);
+    if (coef == coef && coef > 1.0e4f) coef = 1.0e4f;
+    for (int k = lane; k <= d; k += 64) ms.sv[k] = (coef * (ms.sy[k] + m * ms.sx[k])) * w;     // w * log_map
+    hm_wave_lds_sync();
+    // exp_map (:73-93)
+    float n2 = hm_halfwave_sum(d, lane, [&](int e) { return ms.sv[1 + e] * ms.sv[1 + e]; });
+    if (n2 == n2 && n2 < 1.0e-8f) n2 = 1.0e-8f;
+    const float nn = __builtin_sqrtf(n2);
+    const float ch = hm::cosh_c(nn), sh = hm::sinh_c(nn);
+    for (int k = lane; k <= d; k += 64) ms.so[k] = ch * ms.sx[k] + sh * (ms.sv[k] / nn);
+    hm_wave_lds_sync();
+    float r2 = 0.0f;
+    if (project) {
+        // project (:41-56): sequential fmaf chain, every lane the same (LDS broadcast reads)
+        for (int k = 1; k <= d; ++k) r2 = __builtin_fmaf(ms.so[k], ms.so[k], r2);
+        const float rr = __builtin_sqrtf(r2);
+        const float x0 = __builtin_sqrtf(1.0f + (c * rr) * rr);
+        hm_wave_lds_sync();
+        if (lane == 0) ms.so[0] = x0;
+        hm_wave_lds_sync();
+    }
+    return r2;
+}
+
+// write ms.so as row `row` of the caller's table (may be nullptr), of the fp32 image and of the bf16 image, and
+// fold its norms into the bounds the pair scan's error margin uses
+__device__ __forceinline__ void hm_wave_store_row(MidScratch& ms, float r2, int d, int RS, int KS, float* __restrict__ X, int64_t ld,
+                                                  float* __restrict__ img, unsigned char* __restrict__ img16, int64_t row,
+                                                  uint32_t* __restrict__ rmax2_bits, int lane)
+{
+    if (lane == 0) {
+        const float x0 = ms.so[0];
+        const float q2 = __builtin_fmaf(x0, x0, r2);
+        if (q2 < 3.0e38f && q2 > 0.0f) {
+            atomicMax(rmax2_bits, hm::fbits(q2 * 1.0001f));
+            if (r2 > 0.0f) atomicMax(rmax2_bits + 1, hm::fbits(r2 * 1.0001f));
+        }
+    }
+    float* ir = img + row * RS;
+    for (int k = lane; k <= d; k += 64) {
+        const float v = ms.so[k];
+        if (X != nullptr) X[row * ld + k] = v;
+        if (k == 0) ir[RS - 4] = v;
+        else ir[hm_img_off(k - 1)] = v;
+    }
+    const int CH = 2 * KS + 1;
+    for (int cidx = lane; cidx < CH; cidx += 64) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (cidx == CH - 1) v.x = hm::fbits(ms.so[0]);
+        else v = hm_bf16_chunk(ms.so + 1, ms.so[0], d, KS, cidx);
+        *reinterpret_cast<uint4*>(img16 + ((int64_t)row * CH + cidx) * 16) = v;
+    }
+}

@@ -1,0 +1,657 @@
+// hm_scan.hip -- the pair scan: X.G.X^T on the matrix cores as a PREFILTER for the exact search.
+//
+// Replaces the N x N distance matrix of the reference (batch_distance + triu + "< thr" + nonzero,
+// tokenizer/hyperbolic_merge.py:247-269, fast_hyperbolic_merge.py:336-355); never materialises it.
+//
+// Shape.  Block = WPB waves; each wave keeps 32*TM *stationary* rows as MFMA A-fragments in registers for the
+// whole block; the *partner* rows stream through LDS as tiles of 32*SUB rows, filled by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction) into a ring of slots.  Every wave issues the same
+// number of pieces per tile, so "tile landed" is a counted s_waitcnt vmcnt(N) followed by one s_barrier per tile.
+// A tile is walked as SUB groups of 32 columns.  Two accumulator sets alternate between groups: while the MFMAs
+// of group g fill one set, the bound test of group g-1 (v_max3 tree, compare, ballot) runs on the other, in the
+// same basic block -- the matrix pipe never drains for an epilogue, and the first LDS fragment of group g+1 is
+// requested before the branch that ends group g.
+//
+// Two prefilter forms, one result (every reported distance is re-evaluated canonically, hm_search.hip):
+//   BF = 0  v_mfma_f32_32x32x2_f32 on the fp32 image (exact fmaf chain; NG = groups of 4 spatial coordinates)
+//   BF = 1  v_mfma_f32_32x32x16_bf16 on the bf16 image (NG = k-steps of 16; time coordinate in split slots)
+// A bound delta >= |u_f - u_c| (hm_scan_delta) widens every comparison.
+#include <type_traits>
+
+#include "hm_common.h"
+
+#pragma clang fp contract(off)
+
+#ifndef HM_SUB_BF16
+#define HM_SUB_BF16 4              // bf16 form: 32-column groups per streamed tile (128 partner rows per barrier)
+#endif
+#ifndef HM_SUB_F32
+#define HM_SUB_F32 2
+#endif
+#ifndef HM_DIST_BF16
+#define HM_DIST_BF16 1             // tiles in flight ahead of the computed one (ring of DIST + 1 slots)
+#endif
+#ifndef HM_WPB_BIG
+#define HM_WPB_BIG 8               // bf16 form, large launches: 8 waves x 64 rows = 512-row blocks (half the L2 -> LDS fill traffic)
+#endif
+#ifndef HM_SCAN_INSTANTIATE_ALL
+#define HM_SCAN_INSTANTIATE_ALL 1  // 0: only d = 100 (KS = 7 / NG = 25) -- quick builds for tuning runs
+#endif
+
+// CNT (1..4) consecutive 1 KiB LDS-DMA pieces in one statement: one M0 write; the immediate offset of
+// global_load_lds applies to the global and to the LDS address alike, so the pieces share both bases.
+template <int CNT>
+__device__ __forceinline__ void hm_dma_group(const char* src, uint32_t dst)
+{
+    uint32_t keep;
+    if constexpr (CNT == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else if constexpr (CNT == 3)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else if constexpr (CNT == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                     "global_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+// PIECES consecutive pieces starting at piece index FIRST, four per statement
+template <int PIECES, int FIRST = 0>
+__device__ __forceinline__ void hm_dma_run(const char* src, uint32_t dst)
+{
+    if constexpr (FIRST < PIECES) {
+        hm_dma_group<(PIECES - FIRST < 4 ? PIECES - FIRST : 4)>(src + FIRST * 1024, dst + FIRST * 1024u);
+        hm_dma_run<PIECES, FIRST + 4>(src, dst);
+    }
+}
+
+template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int SUB>
+__global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
+{
+    static_assert(SUB % 2 == 0, "the two accumulator sets alternate between column groups: an even number per tile");
+    constexpr int COLS = 32 * SUB;                 // partner rows per streamed tile
+    constexpr int RS = hm_row_floats(NG);          // fp32 image: floats per row
+    constexpr int RB16 = 32 * NG + 16;             // bf16 image: bytes per row (NG x 16 bf16 + [x0 fp32, pad])
+    constexpr int ROW_BYTES = BF ? RB16 : RS * 4;
+    constexpr int TILE_BYTES = COLS * ROW_BYTES;
+    constexpr int NP = BF ? NG : NG + 1;           // k-steps: fp32: NG spatial groups + time; bf16: NG steps of 16
+    constexpr int NPIECE = TILE_BYTES / 1024;      // 1 KiB pieces per tile
+    constexpr int TCH = RS / 4 - 1;                // fp32 image: chunk index of the time group
+    constexpr int PPW = (NPIECE + WPB - 1) / WPB;  // LDS-DMA pieces per wave and tile (slot padded to PPW * WPB KiB)
+    constexpr int TILE_LDS = PPW * WPB * 1024;     // LDS bytes per ring slot
+    constexpr int DIST = BF ? HM_DIST_BF16 : 1;    // tiles in flight ahead of the one being computed
+    constexpr int NBUF = DIST + 1;                 // ring slots
+    constexpr int WAVE_ROWS = 32 * TM;
+    constexpr int BLOCK_ROWS = WPB * WAVE_ROWS;
+    constexpr int NTHREADS = 64 * WPB;
+    static_assert(TILE_BYTES % 1024 == 0, "tiles are moved in 1 KiB pieces");
+    static_assert(DIST * PPW <= 60, "the counted wait must fit vmcnt");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF * TILE_LDS (+ hist)
+
+    if (p.stop != nullptr && *p.stop != 0u) return;     // a device-resident loop has ended
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    uint32_t sure_total = 0;             // per-lane partial of the sure count
+    unsigned long long gk = ~0ull;       // last value read of the running argmin key
+    unsigned long long gk_raw = ~0ull;   // destination of the asynchronous key load
+    bool gk_pending = false;
+    const uint32_t lds_base = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)smem);
+
+    uint32_t* lhist = nullptr;
+    if (MODE == HM_MODE_HIST) {
+        lhist = reinterpret_cast<uint32_t*>(smem + NBUF * TILE_LDS);
+        for (int t = threadIdx.x; t < HM_HIST_BINS; t += NTHREADS) lhist[t] = 0;
+    }
+
+    // ---- which (row block, run of column tiles) this block owns ----
+    int rb, ct0, ct1;
+    if ((int)blockIdx.x < p.n_items_a) {
+        rb = p.rb_first + (int)blockIdx.x / p.chunks_a;
+        ct0 = p.ctmin_a + ((int)blockIdx.x % p.chunks_a) * p.ch_a;
+        ct1 = ct0 + p.ch_a;
+    } else {
+        const int it = (int)blockIdx.x - p.n_items_a;
+        rb = p.rb_split + it / p.chunks_b;
+        ct0 = p.ctmin_b + (it % p.chunks_b) * p.ch_b;
+        ct1 = ct0 + p.ch_b;
+    }
+    if (ct0 < (rb * BLOCK_ROWS) / COLS) ct0 = (rb * BLOCK_ROWS) / COLS;   // left of the diagonal: no i < j
+    if (ct1 > p.nct) ct1 = p.nct;
+    if (ct0 >= ct1) return;
+
+    const int i0w = rb * BLOCK_ROWS + wave * WAVE_ROWS;   // first stationary row of this wave
+    const bool wave_active = (i0w < p.row_end) && (i0w + WAVE_ROWS - 1 >= p.row_begin) && (i0w < p.n);
+    const bool rows_full = (i0w >= p.row_begin) && (i0w + WAVE_ROWS - 1 < p.row_end);
+
+    // The MFMA result u_f (plain fmaf chain) and the canonical u_c (torch reduction order) are two
+    // roundings of the same exact form; |u_f - u_c| <= delta (gamma_n bound on both, |terms| <= rmax2).
+    const float delta = hm_scan_delta(BF != 0, BF ? 16 * NG : RS, p.rmax2_bits);
+    const float pre_f = p.u_hi + delta;              // candidate prefilter on u_f
+    const float lo_f = p.u_lo - delta;               // u_f below this: canonical d < thr for sure
+    const float zmax_f = 1.0f - delta;               // u_f at or below this: canonical u <= 1, d == 0
+    const bool cut_all = (p.cut_bits == 0xffffffffu);
+    const float cut_f = cut_all ? p.u_hi : hm::bitsf(p.cut_bits) + delta;
+
+    // the running argmin key as it stands when the block starts (seeded, or found by earlier blocks)
+    if (MODE == HM_MODE_ARGMIN) {
+        const unsigned long long g0 = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g0 < gk) gk = g0;
+    }
+
+    // ---- stationary A fragments: lane (r, h) keeps its operands of every k-step in registers ----
+    float2 a[BF ? 1 : TM][BF ? 1 : NP];            // fp32 form: 2 operands (two k-steps) per group
+    uint4 a16[BF ? TM : 1][BF ? NP : 1];           // bf16 form: 8 bf16 per 16-wide k-step
+    if constexpr (BF) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const unsigned char* src = p.img16 + (int64_t)(i0w + 32 * tm + r) * RB16 + 16 * h;
+#pragma unroll
+            for (int g = 0; g < NP; ++g) a16[tm][g] = *reinterpret_cast<const uint4*>(src + 32 * g);
+            // stationary side of the time product: [hi, lo, hi, 0] -> [-hi, -hi, -lo, 0] (last 4 slots,
+            // held by the h = 1 half of the last k-step)
+            if (h == 1) {
+                const uint32_t z = a16[tm][NP - 1].z;
+                const uint32_t hi16 = z & 0xffffu, lo16 = z >> 16;
+                a16[tm][NP - 1].z = (hi16 | (hi16 << 16)) ^ 0x80008000u;
+                a16[tm][NP - 1].w = lo16 ^ 0x8000u;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const float* src = p.img + (int64_t)(i0w + 32 * tm + r) * RS + 2 * h;
+#pragma unroll
+            for (int g = 0; g < NP; ++g) a[tm][g] = *reinterpret_cast<const float2*>(src + 4 * (g < NG ? g : TCH));
+            a[tm][NG].x = -a[tm][NG].x;            // time step: acc = S - x0*y0 = -M
+        }
+    }
+
+    // ---- LDS-DMA of one tile: wave w moves the PPW consecutive pieces [w * PPW, (w + 1) * PPW), four per
+    // statement, through inline asm so that hipcc neither sees nor drains them; pieces past NPIECE (slot padding)
+    // read the first KiB of the next tile: in bounds (the image is allocated with slack rows), unused.
+    auto dma_tile = [&](int ct, int buf) {
+        const char* src = (BF ? reinterpret_cast<const char*>(p.img16) : reinterpret_cast<const char*>(p.img)) +
+                          (int64_t)ct * TILE_BYTES + lane * 16 + wave * (PPW * 1024);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * (uint32_t)TILE_LDS + (uint32_t)wave * (PPW * 1024u));
+        hm_dma_run<PPW>(src, dst);
+    };
+
+    // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
+    int ct_step = 1;
+    if (MODE == HM_MODE_HIST) {
+        ct_step = p.sample_stride;
+        ct0 += (ct_step - (ct0 + rb * 7) % ct_step) % ct_step;
+        if (ct0 >= ct1) return;
+    }
+    const int ntile = (ct1 - ct0 + ct_step - 1) / ct_step;
+    auto tile_at = [&](int t) { return ct0 + t * ct_step; };
+
+    // ring prologue: tiles 0 .. DIST-1 in flight (a repeat of the last tile when the run is shorter), tile 0 landed
+#pragma unroll
+    for (int q = 0; q < DIST; ++q) dma_tile(tile_at(q < ntile ? q : ntile - 1), q);
+    if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * PPW) : "memory");
+    // hipcc waits for its own loads (the A fragments above) lazily, at their first use INSIDE the loop -- with
+    // vmcnt(N) instructions that also wait for the ring's LDS-DMA (which it cannot see) on every iteration.
+    // A wait it can see, here, settles them before the loop is entered.
+    if (DIST == 1) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+    __syncthreads();
+
+    // ---- per-group pieces ----
+    f32x16 acc[2][TM];                              // two accumulator sets (see the header)
+    uint4 bpre16 = make_uint4(0, 0, 0, 0);          // first B fragment of the NEXT group, requested by the previous one
+    float2 bpre = make_float2(0.f, 0.f);
+
+    // all k-steps of column group `sub` of ring slot `buf` into acc[set].  `fresh`: the first fragment was not
+    // requested by the previous group (first group of a tile, or the previous group was skipped).  The last k-step
+    // always requests the first fragment of group sub + 1 (for the last group of a tile that lands in the slack
+    // behind the slot and is never used).
+    // `red_c` = true: the bound test's reduction over the OTHER accumulator set (the group finished before) is
+    // folded into the k-steps, a few elements behind each step's MFMAs -- written into the same straight-line code
+    // so that the vector ALU work rides in the matrix instructions' issue shadow; its result goes to `ext`.
+    auto mma_group = [&](auto set_c, auto red_c, int buf, int sub, bool fresh, float& ext) {
+        constexpr int set = decltype(set_c)::value;
+        constexpr bool RED = decltype(red_c)::value;
+        constexpr int QN = 16 * TM;
+        if constexpr (RED) ext = acc[set ^ 1][0][0];
+        auto fold = [&](int g) {
+            if constexpr (RED) {
+#pragma unroll
+                for (int q = (g * QN) / NP; q < ((g + 1) * QN) / NP; ++q) {
+                    const float v = acc[set ^ 1][q / 16][q % 16];
+                    ext = SIGN ? __builtin_fmaxf(ext, v) : __builtin_fminf(ext, v);
+                }
+            }
+        };
+        if constexpr (BF) {
+            const char* bt = smem + buf * TILE_LDS + (sub * 32 + r) * RB16 + 16 * h;
+            if (fresh) bpre16 = *reinterpret_cast<const uint4*>(bt);
+            uint4 bc = bpre16, bn = bc;
+#pragma unroll
+            for (int g = 0; g < NP; ++g) {
+                bn = *reinterpret_cast<const uint4*>(bt + (g + 1 < NP ? 32 * (g + 1) : 32 * RB16));
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    if (g == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
+                                                                              __builtin_bit_cast(bf16x8, bc), z, 0, 0, 0);
+                    } else {
+                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
+                                                                              __builtin_bit_cast(bf16x8, bc), acc[set][tm], 0, 0, 0);
+                    }
+                }
+                fold(g);
+                bc = bn;
+            }
+            bpre16 = bn;
+            // acc = S - x0*y0 (= -M): the time product came out of the last k-step's split slots
+        } else {
+            const float* bt = reinterpret_cast<const float*>(smem + buf * TILE_LDS) + (sub * 32 + r) * RS + 2 * h;
+            if (fresh) bpre = *reinterpret_cast<const float2*>(bt);
+            float2 bc = bpre, bn = bc;
+#pragma unroll
+            for (int g = 0; g < NP; ++g) {
+                bn = *reinterpret_cast<const float2*>(bt + (g + 1 < NP ? 4 * (g + 1 < NG ? g + 1 : TCH) : 32 * RS));
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    if (g == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].x, bc.x, z, 0, 0, 0);
+                    } else {
+                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].x, bc.x, acc[set][tm], 0, 0, 0);
+                    }
+                }
+                if (g < NG) {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][g].y, bc.y, acc[set][tm], 0, 0, 0);
+                }
+                fold(g);
+                bc = bn;
+            }
+            bpre = bn;
+        }
+        if constexpr (RED) ext = SIGN ? -ext : ext;
+    };
+
+    // the lane's most promising u of accumulator set `set` (acc = -M: u = acc under the reference sign, -acc under lorentz)
+    auto reduce_group = [&](auto set_c) -> float {
+        constexpr int set = decltype(set_c)::value;
+        float ext = acc[set][0][0];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ext = SIGN ? __builtin_fmaxf(ext, acc[set][tm][e]) : __builtin_fminf(ext, acc[set][tm][e]);
+        return SIGN ? -ext : ext;
+    };
+
+    // bound test of a finished group and, when some lane is below the bound, the slow path: one 32x32 MFMA tile at
+    // a time (a rolled loop: the hot loop must not inherit its register pressure).  Per-element predicates are
+    // evaluated twice (count, then write); the second evaluation runs on laundered copies of the bounds so that the
+    // compiler does not keep the predicates alive across the wave scan.
+    auto finish_group = [&](auto set_c, float ext_u, int j0s) {
+        constexpr int set = decltype(set_c)::value;
+        float bound_f = pre_f;
+        uint32_t best_bits = 0xffffffffu, best_low = 0xffffffffu;
+        if (MODE == HM_MODE_TOPK && !p.count_sure && !cut_all && cut_f < bound_f) bound_f = cut_f;   // nothing above the cut is visited
+        if (MODE == HM_MODE_ARGMIN) {
+            // an entry can only order before the running best if its u_f is within 2*delta (+ a few ulps of acosh
+            // wiggle) of the best u_f
+            best_bits = (uint32_t)(gk >> 32);
+            best_low = (uint32_t)gk;
+            if (best_bits != 0xffffffffu) {
+                const float bb = hm::bitsf(best_bits + HM_TIE_SLACK) + 2.0f * delta;
+                if (bb < bound_f) bound_f = bb;
+            }
+        }
+        if (__ballot(ext_u < bound_f) == 0ull) return;
+        const bool full = rows_full && (j0s > i0w + WAVE_ROWS - 1) && (j0s + 31 < p.n);
+        unsigned long long wkey = ~0ull;
+        bool wrote = false;
+#pragma unroll 1
+        for (int st = 0; st < TM; ++st) {
+            f32x16 w = acc[set][0];
+#pragma unroll
+            for (int q = 1; q < TM; ++q)
+                if (st == q) w = acc[set][q];
+            if (TM > 1) {
+                float e1 = w[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) e1 = SIGN ? __builtin_fmaxf(e1, w[e]) : __builtin_fminf(e1, w[e]);
+                if (__ballot((SIGN ? -e1 : e1) < bound_f) == 0ull) continue;
+            }
+            uint32_t n_emit = 0, n_sure = 0;
+            float bnd = bound_f;
+            float cutv = cut_f;
+            unsigned long long slot = 0;
+            const int ib = i0w + 32 * st + 4 * h;
+            const int j = j0s + r;
+            auto visit = [&](const float wv, const int e, const bool write) {
+                const float u = SIGN ? -wv : wv;
+                const int i = ib + (e & 3) + 8 * (e >> 2);
+                bool pass = u < bnd;
+                if (!full) pass = pass && (i < j) && (j < p.n) && (i >= p.row_begin) && (i < p.row_end);
+                if (!pass) return;
+                const float up = u < 1.0f ? 1.0f : u;
+                const uint32_t ub = hm::fbits(up);
+                if (MODE == HM_MODE_HIST) {
+                    if (ub >= p.hist_lo) {
+                        uint32_t bin = (ub - p.hist_lo) >> p.hist_shift;
+                        if (bin > HM_HIST_BINS - 1) bin = HM_HIST_BINS - 1;
+                        atomicAdd(&lhist[bin], 1u);
+                    }
+                    return;
+                }
+                bool emit;
+                uint32_t flag = 0;
+                const bool zero = (u <= zmax_f) && (p.thr_pos != 0);     // certainly d == 0 < thr
+                if (MODE == HM_MODE_TOPK) {
+                    const bool sure = zero || (up < lo_f);
+                    if (sure && !write) ++n_sure;
+                    flag = sure ? 1u : 0u;
+                    // zero-distance ties order by (i, j): a tie flood is cut by rows (tie_imax)
+                    emit = zero ? (i <= p.tie_imax) : ((!sure && p.count_sure) || cut_all || up <= cutv);
+                } else {
+                    const uint32_t ubz = zero ? 0x3f7fffffu : ub;
+                    const uint32_t low = ((uint32_t)i << 15) | ((uint32_t)j >> 2);
+                    emit = !(zero && best_bits == 0x3f7fffffu) || (low <= best_low);
+                    if (emit && !write) {
+                        const unsigned long long k = ((unsigned long long)ubz << 32) | low;
+                        wkey = k < wkey ? k : wkey;
+                    }
+                }
+                if (!emit) return;
+                if (!write) { ++n_emit; return; }
+                if (slot < (unsigned long long)p.ent_cap) p.ent[slot] = make_uint4(ub, (uint32_t)i, (uint32_t)j, flag);
+                ++slot;
+            };
+#pragma unroll
+            for (int e = 0; e < 16; ++e) visit(w[e], e, false);
+            if (MODE == HM_MODE_HIST) continue;
+            sure_total += n_sure;
+            const uint32_t incl = hm_wave_incl_scan(n_emit, lane);
+            const uint32_t total = __shfl(incl, 63, 64);
+            if (total == 0) continue;
+            unsigned long long base = 0;
+            if (lane == 63) base = atomicAdd(&p.ctr64[2], (unsigned long long)total);     // 64-bit: a tie flood cannot wrap it
+            base = __shfl(base, 63, 64);
+            slot = base + incl - n_emit;
+            asm volatile("" : "+v"(bnd), "+v"(cutv));      // opaque: no CSE with the count pass
+#pragma unroll
+            for (int e = 0; e < 16; ++e) visit(w[e], e, true);
+            wrote = true;
+        }
+        if (MODE == HM_MODE_ARGMIN && wrote) {
+            const unsigned long long wk = hm_wave_min_u64(wkey);
+            if (lane == 0) atomicMin(&p.ctr64[1], wk);
+            // the slow path has drained the vector-memory queue anyway: refresh the running key now
+            gk = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wk < gk) gk = wk;
+        }
+    };
+
+    bool pend = false;               // a finished group waits in the other accumulator set for its bound test
+    int pend_j0s = 0;
+    int buf = 0;                     // ring slot of tile t
+
+    for (int t = 0; t < ntile; ++t) {
+        const int ct = tile_at(t);
+        const int ct_next = (t + DIST < ntile) ? tile_at(t + DIST) : ct;      // (a repeat of this tile lands in the free slot)
+        int buf_next = buf + DIST;                           // slot of tile t + DIST = slot of tile t - 1:
+        if (buf_next >= NBUF) buf_next -= NBUF;              // every wave left it at the previous barrier
+        const int j0 = ct * COLS;
+
+        // running best key, re-read every 8th tile by a load the compiler does not see (it would wait for it with
+        // vmcnt(0) inside the MFMA loop and so drain the ring): the value is picked up behind this iteration's own
+        // counted wait.  Issued ahead of the tile's DMA, so that wait covers it.
+        if (MODE == HM_MODE_ARGMIN && (t & 7) == 0) {
+            asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(gk_raw) : "v"(&p.ctr64[1]) : "memory");
+            gk_pending = true;
+        }
+        dma_tile(ct_next, buf_next);
+
+        // two groups per pass, the accumulator sets alternating (a rolled loop: two code sites for the slow path)
+#pragma unroll 1
+        for (int sp = 0; sp < SUB / 2; ++sp) {
+            {
+                const int sub = 2 * sp;
+                const int j0s = j0 + sub * 32;
+                const bool do_c = wave_active && (j0s + 31 > i0w);
+                float ext_u = 0.0f;
+                if (do_c && pend) {                           // the common case: one basic block, MFMAs + the other set's test
+                    mma_group(std::integral_constant<int, 0>{}, std::true_type{}, buf, sub, sp == 0, ext_u);
+                } else {
+                    if (do_c) mma_group(std::integral_constant<int, 0>{}, std::false_type{}, buf, sub, true, ext_u);
+                    if (pend) ext_u = reduce_group(std::integral_constant<int, 1>{});
+                }
+                if (pend) finish_group(std::integral_constant<int, 1>{}, ext_u, pend_j0s);
+                pend = do_c;
+                pend_j0s = j0s;
+            }
+            {
+                const int sub = 2 * sp + 1;
+                const int j0s = j0 + sub * 32;
+                const bool do_c = wave_active && (j0s + 31 > i0w);
+                float ext_u = 0.0f;
+                if (do_c && pend) {                           // the previous group ran: its last k-step requested our first fragment
+                    mma_group(std::integral_constant<int, 1>{}, std::true_type{}, buf, sub, false, ext_u);
+                } else {
+                    if (do_c) mma_group(std::integral_constant<int, 1>{}, std::false_type{}, buf, sub, true, ext_u);
+                    if (pend) ext_u = reduce_group(std::integral_constant<int, 0>{});
+                }
+                if (pend) finish_group(std::integral_constant<int, 0>{}, ext_u, pend_j0s);
+                pend = do_c;
+                pend_j0s = j0s;
+            }
+        }
+
+        // tile t+1 has landed (this wave's pieces) -- and so has the key load, if one was issued
+        if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gk_raw) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gk_raw) : "n"((DIST - 1) * PPW) : "memory");
+        if (MODE == HM_MODE_ARGMIN && gk_pending) {
+            if (gk_raw < gk) gk = gk_raw;                   // the key only ever decreases
+            gk_pending = false;
+        }
+        __syncthreads();                                     // ... and every wave's; all reads of slot `buf` done
+        if (++buf == NBUF) buf = 0;
+    }
+    if (pend) {                                              // the last group of the run (set (SUB - 1) % 2 = 1)
+        const float ext_u = reduce_group(std::integral_constant<int, 1>{});
+        finish_group(std::integral_constant<int, 1>{}, ext_u, pend_j0s);
+    }
+
+    if (MODE == HM_MODE_TOPK) {
+        // one 64-bit atomic per wave for the sure count
+        unsigned long long s = sure_total;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0 && s != 0) atomicAdd(&p.ctr64[0], s);
+    }
+    if (MODE == HM_MODE_HIST) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < HM_HIST_BINS; t += NTHREADS)
+            if (lhist[t]) atomicAdd(&p.hist[t], lhist[t]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch
+// ------------------------------------------------------------------------------------------------
+template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int SUB>
+static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    const size_t tile_bytes = (size_t)32 * SUB * (BF ? (32 * NG + 16) : 4 * hm_row_floats(NG));
+    const size_t ppw = (tile_bytes / 1024 + WPB - 1) / WPB;
+    size_t lds = ((BF ? HM_DIST_BF16 : 1) + 1) * ppw * WPB * 1024;
+    lds += (size_t)32 * (BF ? (32 * NG + 16) : 4 * hm_row_floats(NG));     // slack behind the ring: the early request of "the next group's" fragment
+    if (MODE == HM_MODE_HIST) lds += sizeof(uint32_t) * HM_HIST_BINS;      // (HIST mode keeps its bins there; they are only read by that request)
+    const void* fn = reinterpret_cast<const void*>(&hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>);
+    if (lds > 48 * 1024 && e->attr_done.find(fn) == e->attr_done.end()) {     // per engine (= per device), not process-wide
+        hipError_t st = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (st != hipSuccess) return st;
+        e->attr_done.insert(fn);
+    }
+    // timed launches carry their events in the dispatch itself (start / stop timestamps of this kernel): a pair of
+    // hipEventRecord calls around it costs two ~6 us bubbles on the stream
+    if (ev0 != nullptr) hipExtLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int NG, int BF, int TM, int WPB, int SUB>
+static hipError_t hm_launch_scan_ng(hm_engine* e, int sign, int mode, const ScanArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0,
+                                    hipEvent_t ev1)
+{
+    if (sign) {
+        if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 1, HM_MODE_TOPK, BF, TM, WPB, SUB>(e, a, grid, s, ev0, ev1);
+        if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 1, HM_MODE_ARGMIN, BF, TM, WPB, SUB>(e, a, grid, s, ev0, ev1);
+        return hm_launch_scan_t<NG, 1, HM_MODE_HIST, BF, TM, WPB, SUB>(e, a, grid, s, ev0, ev1);
+    }
+    if (mode == HM_MODE_TOPK) return hm_launch_scan_t<NG, 0, HM_MODE_TOPK, BF, TM, WPB, SUB>(e, a, grid, s, ev0, ev1);
+    if (mode == HM_MODE_ARGMIN) return hm_launch_scan_t<NG, 0, HM_MODE_ARGMIN, BF, TM, WPB, SUB>(e, a, grid, s, ev0, ev1);
+    return hm_launch_scan_t<NG, 0, HM_MODE_HIST, BF, TM, WPB, SUB>(e, a, grid, s, ev0, ev1);
+}
+
+// Which prefilter form a scan uses.  The bf16 form's error bound 0.00392 * max||x_s||^2 only costs
+// extra emissions, never correctness; auto picks it from d >= 24 (below that the fp32 form is already short).
+bool hm_use_bf16(const hm_engine* e)
+{
+    if (!e->bf16_ok || e->force_f32) return false;
+    if (e->precision == HM_PREFILTER_F32) return false;
+    if (e->precision == HM_PREFILTER_BF16) return true;
+    return e->d >= 24;
+}
+
+hipError_t hm_launch_scan(hm_engine* e, int mode, const ScanArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
+{
+    if (a.bf16 && a.shape == 1) {
+        switch (e->KS) {
+#if HM_SCAN_INSTANTIATE_ALL
+            case 1: return hm_launch_scan_ng<1, 1, 2, HM_WPB_BIG, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 2: return hm_launch_scan_ng<2, 1, 2, HM_WPB_BIG, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 4: return hm_launch_scan_ng<4, 1, 2, HM_WPB_BIG, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 8: return hm_launch_scan_ng<8, 1, 2, HM_WPB_BIG, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+#endif
+            case 7: return hm_launch_scan_ng<7, 1, 2, HM_WPB_BIG, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        }
+        return hipErrorInvalidValue;
+    }
+    if (a.bf16) {
+        switch (e->KS) {
+#if HM_SCAN_INSTANTIATE_ALL
+            case 1: return hm_launch_scan_ng<1, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 2: return hm_launch_scan_ng<2, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 4: return hm_launch_scan_ng<4, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+            case 8: return hm_launch_scan_ng<8, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+#endif
+            case 7: return hm_launch_scan_ng<7, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        }
+        return hipErrorInvalidValue;
+    }
+    switch (e->NG) {
+#if HM_SCAN_INSTANTIATE_ALL
+        case 1: return hm_launch_scan_ng<1, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 2: return hm_launch_scan_ng<2, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 3: return hm_launch_scan_ng<3, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 4: return hm_launch_scan_ng<4, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 6: return hm_launch_scan_ng<6, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 8: return hm_launch_scan_ng<8, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 10: return hm_launch_scan_ng<10, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 13: return hm_launch_scan_ng<13, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 16: return hm_launch_scan_ng<16, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 20: return hm_launch_scan_ng<20, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 28: return hm_launch_scan_ng<28, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 32: return hm_launch_scan_ng<32, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+#endif
+        case 25: return hm_launch_scan_ng<25, 0, 2, 4, HM_SUB_F32>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+    }
+    return hipErrorInvalidValue;
+}
+
+// common argument preparation; returns false when the row range is empty
+bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t row_end, ScanArgs& a, dim3& grid, int64_t n_limit)
+{
+    // n_limit: search among the first n_limit rows only (rows are only ever appended: the pairs of an earlier table)
+    const int64_t n = (n_limit >= 0 && n_limit < e->n) ? n_limit : e->n;
+    if (row_end < 0 || row_end > n) row_end = n;
+    if (row_begin < 0) row_begin = 0;
+    if (row_end > n - 1) row_end = n - 1;        // the last row has no partner j > i
+    if (row_begin >= row_end) return false;
+    memset(&a, 0, sizeof(a));
+    a.img = e->img;
+    a.img16 = e->img16;
+    a.bf16 = hm_use_bf16(e) ? 1 : 0;
+    // large launches: 512-row blocks halve the L2 -> LDS fill traffic, which is what limits the bf16 form once the
+    // launch tail no longer does (decided by the pairs this launch covers: a row-range search of a sharded run is
+    // a small launch)
+    a.shape = (a.bf16 && hm_pairs_in_range(n, row_begin, row_end) >= e->big_min_rows * (e->big_min_rows - 1) / 2) ? 1 : 0;
+    const int block_rows = a.bf16 ? (a.shape ? 64 * HM_WPB_BIG : 256) : 256;
+    const int cols = 32 * (a.bf16 ? HM_SUB_BF16 : HM_SUB_F32);     // partner rows per streamed tile
+    a.n = (int)n;
+    a.row_begin = (int)row_begin;
+    a.row_end = (int)row_end;
+    a.rb_first = (int)(row_begin / block_rows);
+    a.nct = (int)((n + cols - 1) / cols);
+    a.u_hi = b.u_hi;
+    a.u_lo = b.u_lo;
+    a.thr_pos = b.thr_pos;
+    a.count_sure = 1;
+    a.cut_bits = 0xffffffffu;
+    a.tie_imax = 0x7fffffff;
+    a.ent = e->ent;
+    a.ent_cap = e->ent_cap;
+    a.ctr64 = e->d_ctr64;
+    a.hist = e->d_hist;
+    a.sample_stride = 1;
+    a.rmax2_bits = e->d_rmax2;
+    a.stop = nullptr;
+    const int rb_last = (int)((row_end - 1) / block_rows);
+    const int nrb = rb_last - a.rb_first + 1;
+    // diagonal advance per row block in tiles (rounded down: the kernel clamps to the exact diagonal)
+    const int tiles_per_rb = std::max(1, block_rows / cols);
+    // column tiles per block: amortise the stationary-row load, but keep enough blocks in flight.
+    // (the knob is in 64-column units, as in round 1)
+    int ch = (a.bf16 ? e->chunk_bf16 : e->chunk_f32) * 64 / cols;
+    if (ch < 1) ch = 1;
+    while (ch > 4 && (int64_t)nrb * ((a.nct + ch - 1) / ch) < 1024) ch >>= 1;
+    // phase B = the last ~tail_fraction of the work (row blocks near the bottom of the triangle), cut into
+    // chunks a quarter the size
+    a.ctmin_a = (int)((int64_t)a.rb_first * block_rows / cols);
+    int rb_split = rb_last + 1;
+    int ch_b = ch;
+    if (ch >= 8 && nrb >= 16) {
+        double total = 0.0, acc = 0.0;
+        for (int rb = a.rb_first; rb <= rb_last; ++rb) total += (double)std::max(0, a.nct - rb * tiles_per_rb);
+        for (int rb = rb_last; rb >= a.rb_first; --rb) {
+            acc += (double)std::max(0, a.nct - rb * tiles_per_rb);
+            if (acc >= e->tail_fraction * total) { rb_split = rb; break; }
+        }
+        ch_b = std::max(1, ch / e->tail_div);
+    }
+    a.ch_a = ch;
+    a.chunks_a = std::max(1, (a.nct - a.ctmin_a + ch - 1) / ch);
+    a.rb_split = rb_split;
+    a.ch_b = ch_b;
+    a.ctmin_b = (int)((int64_t)rb_split * block_rows / cols);
+    a.chunks_b = std::max(1, (a.nct - a.ctmin_b + ch_b - 1) / ch_b);
+    a.n_items_a = (rb_split - a.rb_first) * a.chunks_a;
+    const int n_items_b = (rb_last + 1 - rb_split) * a.chunks_b;
+    grid = dim3((unsigned)std::max(1, a.n_items_a + n_items_b), 1, 1);
+    return true;
+}

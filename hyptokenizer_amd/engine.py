@@ -20,6 +20,9 @@ from . import _lib
 from ._lib import SIGN_LORENTZ, SIGN_REFERENCE, HypMergeError, HypMergeUnavailable  # noqa: F401
 
 SIGN_MODES = {"reference": SIGN_REFERENCE, "lorentz": SIGN_LORENTZ}
+PREFILTERS = {"auto": _lib.PREFILTER_AUTO, "f32": _lib.PREFILTER_F32, "bf16": _lib.PREFILTER_BF16}
+MAX_ROWS = 131072        # hm_engine_create: largest table
+MAX_WIDTH = 129          # ... and widest row (d + 1)
 
 
 def sign_mode_id(sign_convention) -> int:
@@ -44,8 +47,13 @@ def _np_ptr(a: np.ndarray) -> C.c_void_p:
 class MergeEngine:
     """Handle of one ``hm_engine`` (include/hypmerge.h)."""
 
-    def __init__(self, max_rows: int, d1: int, sign_convention="reference", device: Optional[torch.device] = None):
+    def __init__(self, max_rows: int, d1: int, sign_convention="reference", device: Optional[torch.device] = None,
+                 prefilter: str = "auto"):
+        """``prefilter``: form of the pair scan's MFMA prefilter -- "auto" (bf16 from d >= 24), "f32", "bf16".
+        Results do not depend on it (every reported distance is re-evaluated in the canonical fp32 arithmetic)."""
         self._L = _lib.load()
+        if prefilter not in PREFILTERS:
+            raise ValueError(f"prefilter must be one of {sorted(PREFILTERS)}, got {prefilter!r}")
         if not torch.cuda.is_available():
             raise HypMergeUnavailable("MergeEngine needs a HIP device (torch.cuda.is_available() is False); "
                                       "there is no CPU fallback")
@@ -58,7 +66,8 @@ class MergeEngine:
         self.sign_mode = sign_mode_id(sign_convention)
         self._h = C.c_void_p(0)
         _lib.check(self._L.hm_engine_create(C.byref(self._h), self.device.index, self.max_rows, self.d1,
-                                            self.sign_mode))
+                                            self.sign_mode, PREFILTERS[prefilter]))
+        self._rec_buf = np.zeros(4 * _lib.LOOP_MAX_STEPS, np.uint32)
 
     # ------------------------------------------------------------------------------------------
     def close(self) -> None:
@@ -125,18 +134,33 @@ class MergeEngine:
         self._chk(self._L.hm_pairwise_argmin_dev(self._h, float(c), float(thr), int(row_begin), int(row_end),
                                                  _ptr(rec), self._stream()))
 
-    def topk(self, c: float, thr: float, k: int, row_begin: int = 0, row_end: int = -1):
-        """k smallest candidates (d, i, j) in order and the exact candidate count."""
+    def topk(self, c: float, thr: float, k: int, row_begin: int = 0, row_end: int = -1, count: bool = True):
+        """k smallest candidates (d, i, j) in order and the exact candidate count.  ``count=False``: the
+        count is -1 when at least k candidates exist (not counted: the scan then only visits what lies below
+        its emission cut; ``count_candidates`` delivers the number later)."""
         k = int(k)
         d = np.empty(k, np.float32)
         i = np.empty(k, np.int32)
         j = np.empty(k, np.int32)
-        n_out, count = C.c_int64(0), C.c_int64(0)
-        self._chk(self._L.hm_pairwise_topk(self._h, float(c), float(thr), k, int(row_begin), int(row_end),
-                                           _np_ptr(d), _np_ptr(i), _np_ptr(j), C.byref(n_out), C.byref(count),
-                                           self._stream()))
+        n_out, total = C.c_int64(0), C.c_int64(0)
+        fn = self._L.hm_pairwise_topk if count else self._L.hm_pairwise_topk_nocount
+        self._chk(fn(self._h, float(c), float(thr), k, int(row_begin), int(row_end),
+                     _np_ptr(d), _np_ptr(i), _np_ptr(j), C.byref(n_out), C.byref(total), self._stream()))
         m = int(n_out.value)
-        return d[:m], i[:m], j[:m], int(count.value)
+        return d[:m], i[:m], j[:m], int(total.value)
+
+    def count_candidates(self, c: float, thr: float, n_limit: int = -1) -> int:
+        """Exact number of candidates among the first ``n_limit`` rows (-1: all live rows)."""
+        total = C.c_int64(0)
+        self._chk(self._L.hm_pairwise_count(self._h, float(c), float(thr), int(n_limit), C.byref(total), self._stream()))
+        return int(total.value)
+
+    def set_prefilter(self, prefilter: str) -> None:
+        self._chk(self._L.hm_set_prefilter(self._h, PREFILTERS[prefilter]))
+
+    def debug_force_cut(self, cut_bits: int, k: int, c: float) -> None:
+        """test hook (include/hypmerge.h hm_debug_force_cut)"""
+        self._chk(self._L.hm_debug_force_cut(self._h, int(cut_bits), int(k), float(c)))
 
     def candidates(self, c: float, thr: float, row_begin: int = 0, row_end: int = -1, cap: int = 1 << 24):
         """All candidates in row-major order: (i, j, d, total)."""
@@ -182,6 +206,82 @@ class MergeEngine:
             raise ValueError("new_row outside the table")
         self._chk(self._L.hm_merge_append(self._h, int(i), int(j), float(w), float(c), _ptr(t), t.stride(0),
                                           int(new_row), self._stream()))
+
+    def merge_append_batch(self, I, J, W, c: float, table: torch.Tensor, first_row: int) -> None:
+        """Several merges in one launch: merge t -> row first_row + t (may read rows of earlier merges)."""
+        t = self._check_table(table)
+        ti, tj = self._idx(I), self._idx(J)
+        tw = torch.as_tensor(np.ascontiguousarray(W, dtype=np.float32), device=self.device)
+        if not (0 <= first_row and first_row + ti.numel() <= t.shape[0]):
+            raise ValueError("merge batch outside the table")
+        self._chk(self._L.hm_merge_append_batch(self._h, _ptr(ti), _ptr(tj), _ptr(tw), ti.numel(), float(c), _ptr(t),
+                                                t.stride(0), int(first_row), self._stream()))
+
+    def truncate(self, n_rows: int) -> None:
+        self._chk(self._L.hm_truncate(self._h, int(n_rows), self._stream()))
+
+    # -- device-resident loops ----------------------------------------------------------------------
+    def set_token_lengths(self, lengths) -> None:
+        a = np.ascontiguousarray(lengths, dtype=np.int32)
+        self._chk(self._L.hm_set_token_lengths(self._h, _np_ptr(a), a.shape[0], self._stream()))
+
+    def _unpack(self, steps: int):
+        r = self._rec_buf[:4 * steps].reshape(steps, 4)
+        return [(int(f), float(np.uint32(b).view(np.float32)), int(i), int(j)) for f, b, i, j in r.tolist()]
+
+    def std_merge_steps(self, c: float, thr: float, table: torch.Tensor, steps: int):
+        """``steps`` (<= 64) iterations of the standard loop on the device -> (records, done);
+        record = (found, d, i, j): found 1 merged, 0 no candidate, 2 overflow at this step, 3 skipped."""
+        t = self._check_table(table)
+        done = C.c_int64(0)
+        self._chk(self._L.hm_std_merge_steps(self._h, float(c), float(thr), _ptr(t), t.stride(0), int(steps),
+                                             _np_ptr(self._rec_buf), C.byref(done), self._stream()))
+        return self._unpack(int(steps)), int(done.value)
+
+    def incr_merge_steps(self, c: float, thr: float, table: torch.Tensor, steps: int, best):
+        """``steps`` iterations with the nearest pair maintained incrementally; ``best`` = (d, i, j) of the
+        current table or None -> (records, done, best after the last executed step)."""
+        t = self._check_table(table)
+        b = np.zeros(4, np.uint32)
+        if best is not None:
+            b[0] = 1
+            b[1] = np.float32(best[0]).view(np.uint32)
+            b[2], b[3] = best[1], best[2]
+        done = C.c_int64(0)
+        self._chk(self._L.hm_incr_merge_steps(self._h, float(c), float(thr), _ptr(t), t.stride(0), int(steps),
+                                              _np_ptr(b), _np_ptr(self._rec_buf), C.byref(done), self._stream()))
+        nb = (float(b[1:2].view(np.float32)[0]), int(b[2]), int(b[3])) if b[0] == 1 else None
+        return self._unpack(int(steps)), int(done.value), nb
+
+    # -- enhanced tokenizer (config 5) ----------------------------------------------------------------
+    def coherence_distances(self, I, J, W, S, c: float) -> np.ndarray:
+        """distance(exp_map(x_i, w * log_map(x_i, x_j)), x_s) for every candidate t and its samples S[t, :]
+        (enhanced_fast_hyperbolic_merge.py:308-333) -> float32 [b, ns]."""
+        ti, tj = self._idx(I), self._idx(J)
+        tw = torch.as_tensor(np.ascontiguousarray(W, dtype=np.float32), device=self.device)
+        S = np.ascontiguousarray(S, dtype=np.int32).reshape(ti.numel(), -1)
+        ts = torch.as_tensor(S, device=self.device)
+        out = torch.empty(S.shape, dtype=torch.float32, device=self.device)
+        if S.size:
+            self._chk(self._L.hm_coherence_batch(self._h, _ptr(ti), _ptr(tj), _ptr(tw), _ptr(ts), ti.numel(), S.shape[1],
+                                                 float(c), _ptr(out), self._stream()))
+        return out.cpu().numpy()
+
+    def project_table(self, table: torch.Tensor, n_rows: int, c: float) -> None:
+        """``project_to_hyperboloid`` over rows [0, n_rows) of ``table`` in place + image refresh
+        (enhanced_fast_hyperbolic_merge.py:784-792)."""
+        t = self._check_table(table)
+        if n_rows > t.shape[0]:
+            raise ValueError("n_rows outside the table")
+        self._chk(self._L.hm_project_table(self._h, _ptr(t), t.stride(0), int(n_rows), float(c), self._stream()))
+
+    def rows_pair_distance(self, table: torch.Tensor, A, B, c: float) -> np.ndarray:
+        """distance(table[A[t]], table[B[t]]) on ANY rows of the caller's table (not only live image rows)."""
+        t = table.detach()
+        ia = torch.as_tensor(np.ascontiguousarray(A, dtype=np.int64), device=t.device)
+        ib = torch.as_tensor(np.ascontiguousarray(B, dtype=np.int64), device=t.device)
+        out = device_rows_op("distance", t.index_select(0, ia), t.index_select(0, ib), float(c), self.sign_mode)
+        return out.cpu().numpy()
 
     def row_vs_all(self, row: int, n: int, c: float) -> np.ndarray:
         out = torch.empty(int(n), dtype=torch.float32, device=self.device)

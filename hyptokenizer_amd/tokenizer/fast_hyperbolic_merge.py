@@ -48,11 +48,14 @@ class CandidateList(Sequence):
     the reference's cache ever keeps, ``:91-95``) are stored.  Indexing past them raises
     ``IndexError``."""
 
-    def __init__(self, d: np.ndarray, i: np.ndarray, j: np.ndarray, total: int):
+    def __init__(self, d: np.ndarray, i: np.ndarray, j: np.ndarray, total: int, counter=None):
         self._d, self._i, self._j = d, i, j
-        self._total = int(total)
+        self._total = int(total)          # -1: at least len(d) candidates, not counted yet
+        self._counter = counter           # () -> exact total (one counting pass of the engine), used on demand
 
     def __len__(self) -> int:
+        if self._total < 0:
+            self._total = int(self._counter())
         return self._total
 
     @property
@@ -64,7 +67,7 @@ class CandidateList(Sequence):
             idx = range(*k.indices(self.stored))
             return [self[q] for q in idx]
         if k < 0:
-            k += self._total
+            k += len(self)
         if not 0 <= k < self.stored:
             raise IndexError("only the first cache_size candidates of a refresh are materialised")
         return MergeCandidate(float(self._d[k]), int(self._i[k]), int(self._j[k]))
@@ -74,7 +77,7 @@ class CandidateList(Sequence):
             yield self[k]
 
     def __bool__(self) -> bool:
-        return self._total > 0
+        return self._total != 0
 
 
 class AdaptiveMergeCache:
@@ -233,6 +236,9 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         self.hnsw_m = hnsw_m
         self.hnsw_ef_construction = hnsw_ef_construction
         self.hnsw_ef_search = hnsw_ef_search
+        self.lazy_count = True        # refreshes do not count every candidate; len(candidates) counts on demand
+        self.batch_merges = True      # the merges between two refreshes go to the engine as one launch
+        self._refreshed = None        # the CandidateList of this step's refresh (None on a cache pop)
 
     def _build_faiss_index(self) -> None:
         """Reference ``:195-240``.  The HNSW index is replaced by the exact search: nothing to build."""
@@ -245,19 +251,62 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         return [(c.token_i, c.token_j, c.distance) for c in found]
 
     def _find_merge_candidates_fast(self):
-        """Cache pop, else one exact search + cache refill (reference ``:253-376``)."""
+        """Cache pop, else one exact search + cache refill (reference ``:253-376``).
+
+        The refresh asks the engine for the ordered ``cache_size`` best candidates only; ``len()`` of the
+        returned list -- which the reference consumes in two log lines (``:521,526``) -- is the exact
+        number of candidates and is counted on demand (rows are only ever appended, so the pairs of the
+        table as it was at the refresh can be counted at any later time)."""
         cached = self.cache.get_best(100)
+        self._refreshed = None
         if cached:
             return cached
+        self._cancel_plan()
         eng = self._get_engine()
+        c, thr, n0 = self.curvature, self._search_threshold(), self.current_vocab_size
         if self.shard is not None:
             from ..sharding import sharded_topk
-            d, i, j, total = sharded_topk(eng, self.shard, self.curvature, self._search_threshold(), self.cache.max_size)
+            d, i, j, total = sharded_topk(eng, self.shard, c, thr, self.cache.max_size)
+            found = CandidateList(d, i, j, total)
+        elif self.lazy_count and hasattr(eng, "count_candidates"):
+            d, i, j, total = eng.topk(c, thr, self.cache.max_size, count=False)
+            found = CandidateList(d, i, j, total, counter=lambda: eng.count_candidates(c, thr, n0))
         else:
-            d, i, j, total = eng.topk(self.curvature, self._search_threshold(), self.cache.max_size)
-        found = CandidateList(d, i, j, total)
+            d, i, j, total = eng.topk(c, thr, self.cache.max_size)
+            found = CandidateList(d, i, j, total)
         self.cache.add_batch(found)
+        self._refreshed = found
         return found
+
+    def _plan_merges(self, found: "CandidateList", steps_left: int) -> None:
+        """Every merge up to the next refresh is known when a refresh returns (this
+        step merges ``S[0]``, the following ones pop 100 cached entries each and merge the first of them,
+        ``S[0], S[100], S[200], ...``; cached entries are never invalidated).  All of them are issued to the
+        engine as ONE launch; the loop's ``_merge_tokens`` calls then find their rows already written and
+        only do the string bookkeeping.  Capped by the steps the loop has left and by the table size."""
+        cls = type(self)
+        if (not self.batch_merges or self.shard is not None or self._plan
+                or cls._find_merge_candidates_fast is not FastHyperbolicTokenizer._find_merge_candidates_fast
+                or cls._merge_tokens is not FastHyperbolicTokenizer._merge_tokens
+                or {"_merge_tokens", "_find_merge_candidates_fast", "_append_token"} & set(self.__dict__)):
+            return
+        eng = self._get_engine()
+        stored = min(found.stored, self.cache.max_size)
+        if stored == 0 or not hasattr(eng, "merge_append_batch"):
+            return
+        n = self.current_vocab_size
+        picks = [0] + list(range(0, stored, 100))
+        picks = picks[: max(0, min(steps_left, self.max_vocab_size - n))]
+        if len(picks) < 2:
+            return
+        ii = found._i[picks].astype(np.int32)
+        jj = found._j[picks].astype(np.int32)
+        vocab = self.vocab
+        li = np.fromiter((len(vocab[a]) for a in ii.tolist()), np.float64, len(picks))
+        lj = np.fromiter((len(vocab[b]) for b in jj.tolist()), np.float64, len(picks))
+        w = lj / (li + lj)
+        eng.merge_append_batch(ii, jj, w.astype(np.float32), self.curvature, self.embeddings.data, n)
+        self._plan = [(int(a), int(b), n + t) for t, (a, b) in enumerate(zip(ii.tolist(), jj.tolist()))][::-1]
 
     def _merge_tokens(self, i: int, j: int) -> None:
         super()._merge_tokens(i, j)
@@ -315,6 +364,8 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         for step in bar:
             t0 = time.time()
             found = self._find_merge_candidates_fast()
+            if self._refreshed is not None and found:
+                self._plan_merges(self._refreshed, steps - step)
 
             if step % log_every == 0 or not found:
                 ds = self._compute_distance_statistics()

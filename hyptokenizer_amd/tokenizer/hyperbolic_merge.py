@@ -17,7 +17,13 @@ default; "lorentz" = sign-corrected) and ``engine`` (an object 
 the ranks of a process group and every rank applies the same merge to its replica), and
 ``incremental`` (maintain the nearest pair across steps instead of re-searching: rows are only ever
 appended, so after a merge the global minimum is ``min(previous minimum, nearest partner of the new
-row)`` -- one row-vs-all pass per step, same pairs, same distances).
+row)`` -- one row-vs-all pass per step, same pairs, same distances), and ``prefilter``
+("auto" | "f32" | "bf16": the MFMA form of the pair scan; results do not depend on it).
+
+``optimize_merges`` runs its steps in batches ON THE DEVICE (``MergeEngine.std_merge_steps`` /
+``incr_merge_steps``: search -> exact re-evaluation -> merge, step after step without a host round
+trip; the merge weight only needs token lengths, which live in a device array) and replays the
+records on the host afterwards for the token strings -- same pairs, same rows, same log lines.
 The FAISS pre-filter of the reference (``:203-244``, ``:593-625``) is replaced by the exact GPU
 search and never used: ``FAISS_AVAILABLE`` is always False here.
 """
@@ -33,7 +39,7 @@ import torch
 from tqdm import tqdm
 
 from ..embedding.lorentz_model import batch_distance, distance
-from ..engine import HypMergeUnavailable, MergeEngine, sign_mode_id
+from ..engine import MAX_ROWS, MAX_WIDTH, HypMergeUnavailable, MergeEngine, sign_mode_id
 
 logger = logging.getLogger(__name__)
 
@@ -79,6 +85,7 @@ class HyperbolicTokenizer:
         engine=None,
         shard=None,
         incremental: bool = False,
+        prefilter: str = "auto",
     ):
         if device is None:
             device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
@@ -94,6 +101,10 @@ class HyperbolicTokenizer:
         sign_mode_id(sign_convention)
 
         width = embeddings.size(1)
+        if engine is None and (not 2 <= max_vocab_size <= MAX_ROWS or not 2 <= width <= MAX_WIDTH):
+            # the reference accepts any size and fails (or thrashes) later; say it where the object is built
+            raise ValueError(f"the merge engine takes tables of 2..{MAX_ROWS} rows and 2..{MAX_WIDTH} columns "
+                             f"(max_vocab_size={max_vocab_size}, embedding width={width})")
         table = torch.zeros((max_vocab_size, width), dtype=embeddings.dtype, device=self.device)
         table[: self.current_vocab_size] = embeddings.detach().to(self.device)
         self.embeddings = torch.nn.Parameter(table)
@@ -106,7 +117,11 @@ class HyperbolicTokenizer:
         self._engine_key = None       # (table identity, version, rows) the engine image was built from
         self.shard = shard            # hyptokenizer_amd.sharding.ShardContext: row-sharded search over ranks
         self.incremental = bool(incremental)
-        self._inc = None              # incremental search state: (threshold, rows covered, best (d, i, j) | None)
+        self.prefilter = prefilter
+        self._inc = None              # incremental search state: ((threshold, curvature), rows covered, best (d, i, j) | None)
+        self._len_state = None        # (engine id, rows) whose token lengths the engine holds (device-resident loops)
+        self._plan = []               # merges already issued to the engine ahead of the host loop: (i, j, row), next first
+        self.device_loop = True       # optimize_merges may run its steps in batches on the device
 
     # ------------------------------------------------------------------------------------------
     # engine plumbing
@@ -119,7 +134,7 @@ class HyperbolicTokenizer:
                     "HyperbolicTokenizer's candidate search and merge run on a HIP device only "
                     f"(device={self.device}); there is no CPU fallback")
             self._engine = MergeEngine(self.max_vocab_size, self.embeddings.size(1), self.sign_convention,
-                                       self.device)
+                                       self.device, prefilter=self.prefilter)
         key = self._table_key()
         if key != self._engine_key:
             self._engine.set_table(self.embeddings.data, self.current_vocab_size)
@@ -178,19 +193,20 @@ class HyperbolicTokenizer:
         new or stale (table edited, threshold changed), then one row-vs-all reduction per appended
         row.  The key order (d, i, j) is the full search's (distance, then row-major)."""
         eng = self._get_engine()                  # drops self._inc when the table was edited
-        n, thr = self.current_vocab_size, self._search_threshold()
+        n = self.current_vocab_size
+        thr = (self._search_threshold(), float(self.curvature))     # a distance is acosh(u) / sqrt(c): c is part of the key
         st = self._inc
         if st is None or st[0] != thr or st[1] > n:
             if self.shard is not None:
                 from ..sharding import sharded_argmin
-                best = sharded_argmin(eng, self.shard, self.curvature, thr)
+                best = sharded_argmin(eng, self.shard, self.curvature, thr[0])
             else:
-                best = eng.argmin(self.curvature, thr)
+                best = eng.argmin(self.curvature, thr[0])
             rows = n
         else:
             _, rows, best = st
             for r in range(rows, n):              # every rank does this redundantly: no exchange needed
-                cand = eng.row_argmin(r, r, self.curvature, thr)
+                cand = eng.row_argmin(r, r, self.curvature, thr[0])
                 if cand is not None and (best is None or cand < best):
                     best = cand
             rows = n
@@ -204,20 +220,104 @@ class HyperbolicTokenizer:
         li, lj = len(self.vocab[i]), len(self.vocab[j])
         return lj / (li + lj)
 
-    def _merge_tokens(self, i: int, j: int) -> None:
-        """Append the merged token and its embedding (reference ``:309-355``)."""
+    def _append_token(self, i: int, j: int) -> None:
+        """The host half of a merge (reference ``:343-355``): strings, index, history."""
         left, right = self.vocab[i], self.vocab[j]
         merged = left + right
         n = self.current_vocab_size
-        if n >= self.max_vocab_size:
-            raise ValueError(f"Maximum vocabulary size {self.max_vocab_size} reached. Cannot merge more tokens.")
-        eng = self._get_engine()
-        eng.merge_append(i, j, self._merge_weight(i, j), self.curvature, self.embeddings.data, n)
         self.vocab.append(merged)
         self.token2idx[merged] = n
         self.current_vocab_size = n + 1
-        self._engine_key = self._table_key()      # the image already holds row n
         self.merge_history.append((left, right, merged))
+
+    def _merge_tokens(self, i: int, j: int) -> None:
+        """Append the merged token and its embedding (reference ``:309-355``)."""
+        n = self.current_vocab_size
+        if n >= self.max_vocab_size:
+            raise ValueError(f"Maximum vocabulary size {self.max_vocab_size} reached. Cannot merge more tokens.")
+        if self._plan:
+            if self._plan[-1] == (i, j, n):       # issued ahead of time (a batch of merges known in advance): row n is there
+                self._plan.pop()
+                self._append_token(i, j)
+                self._engine_key = self._table_key()
+                return
+            self._cancel_plan()
+        eng = self._get_engine()
+        eng.merge_append(i, j, self._merge_weight(i, j), self.curvature, self.embeddings.data, n)
+        self._append_token(i, j)
+        self._engine_key = self._table_key()      # the image already holds row n
+
+    def _cancel_plan(self) -> None:
+        """The loop left the path a batch of merges was issued for: drop the rows appended ahead of time."""
+        if self._plan:
+            self._plan = []
+            n = self.current_vocab_size
+            self._engine.truncate(n)
+            self.embeddings.data[n:].zero_()
+
+    # ------------------------------------------------------------------------------------------
+    # device-resident batches of the loop
+    # ------------------------------------------------------------------------------------------
+    def _device_loop_ok(self) -> bool:
+        """Steps may run on the device when nothing the batch would bypass is customised: the search and
+        the merge are this class's own (a subclass or an instance attribute that overrides them is
+        honoured by falling back to the step-by-step loop), no row-sharding, an engine that has the loops."""
+        cls = type(self)
+        return (self.device_loop and self.shard is None
+                and cls._merge_tokens is HyperbolicTokenizer._merge_tokens
+                and cls._best_candidate is HyperbolicTokenizer._best_candidate
+                and cls._append_token is HyperbolicTokenizer._append_token
+                and not ({"_merge_tokens", "_best_candidate", "_append_token"} & set(self.__dict__))
+                and hasattr(self._get_engine(), "std_merge_steps"))
+
+    def _sync_token_lengths(self, eng) -> None:
+        n = self.current_vocab_size
+        if self._len_state != (id(eng), n):
+            eng.set_token_lengths([len(t) for t in self.vocab[:n]])
+            self._len_state = (id(eng), n)
+
+    def _device_steps(self, count: int):
+        """Up to ``count`` loop steps in one engine call -> list of (i, j, distance) merged, and whether the
+        loop ran out of candidates.  A step whose search overflowed the engine's emission buffer is run
+        through the step-by-step path (bounded rerun) and the batch resumes after it."""
+        eng = self._get_engine()
+        merged, exhausted = [], False
+        while count > 0 and not exhausted:
+            room = self.max_vocab_size - self.current_vocab_size
+            if room <= 0:
+                raise ValueError(f"Maximum vocabulary size {self.max_vocab_size} reached. Cannot merge more tokens.")
+            k = min(count, 64, room)
+            n = self.current_vocab_size
+            if n <= 100:
+                k = min(k, 101 - n)               # the reference compares differently up to 100 tokens (:270-289): one threshold per batch
+            self._sync_token_lengths(eng)
+            thr = self._search_threshold()            # of the table as it is now; the same for every step of the batch
+            if self.incremental:
+                best = self._best_incremental()
+                recs, done, best_after = eng.incr_merge_steps(self.curvature, thr, self.embeddings.data, k, best)
+            else:
+                recs, done = eng.std_merge_steps(self.curvature, thr, self.embeddings.data, k)
+            for (_f, d, i, j) in recs[:done]:
+                self._append_token(i, j)
+                merged.append((i, j, d))
+            self._engine_key = self._table_key()
+            self._len_state = (id(eng), self.current_vocab_size)
+            if self.incremental:
+                self._inc = ((thr, float(self.curvature)), self.current_vocab_size, best_after)
+            count -= done
+            if done < k:
+                verdict = recs[done][0]
+                if verdict == 2:                      # emission overflow: this one step through the bounded host path
+                    best = self._best_candidate()
+                    if best is None:
+                        exhausted = True
+                    else:
+                        self._merge_tokens(best[0], best[1])
+                        merged.append(best)
+                        count -= 1
+                else:
+                    exhausted = True
+        return merged, exhausted
 
     def optimize_merges(self, steps: int = 10000, log_every: int = 1000, parallel_eval: bool = True,
                         sample_ratio: float = 1.0) -> None:
@@ -225,6 +325,26 @@ class HyperbolicTokenizer:
         change which pair is merged in the reference (``:381-393``, ``:553-591``) and are accepted
         for compatibility."""
         bar = tqdm(range(steps), desc="Optimizing merges", disable=TQDM_OFF)
+        if self._device_loop_ok():
+            step = 0
+            while step < steps:
+                merged, exhausted = self._device_steps(min(64, steps - step))
+                base = self.current_vocab_size - len(merged)
+                for t, (i, j, dist) in enumerate(merged):
+                    if (step + 1) % log_every == 0:
+                        logger.info(f"Step {step+1}: merged '{self.vocab[i]}' + '{self.vocab[j]}' -> "
+                                    f"'{self.vocab[base + t]}' (dist: {dist:.4f})")
+                        logger.info(f"Vocabulary size: {base + t + 1}")
+                    step += 1
+                if not bar.disable:
+                    bar.update(len(merged))
+                    if merged:
+                        bar.set_postfix({"vocab_size": len(self.vocab), "best_dist": merged[-1][2],
+                                         "threshold": self.merge_threshold})
+                if exhausted:
+                    logger.info("No more merge candidates found. Stopping.")
+                    break
+            return
         for step in bar:
             best = self._best_candidate()
             if best is None:
@@ -296,7 +416,7 @@ class HyperbolicTokenizer:
         with open(os.path.join(path, "merges.json"), "w") as f:
             json.dump(self.merge_history, f)
         config = {
-            "curvature": self.curvature,
+            "curvature": self.curvature if isinstance(self.curvature, (int, float)) else float(self.curvature),
             "merge_threshold": self.merge_threshold,
             "embedding_dim": self.embeddings.size(1) - 1,
             "max_vocab_size": self.max_vocab_size,

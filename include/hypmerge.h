@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HM_ABI_VERSION 1
+#define HM_ABI_VERSION 2
 
 #define HM_OK            0
 #define HM_E_ARG        (-1)   /* bad argument (null pointer, range, unsupported dimension) */
@@ -43,6 +43,12 @@ extern "C" {
 
 #define HM_SIGN_REFERENCE 0
 #define HM_SIGN_LORENTZ   1
+
+/* form of the pair scan's MFMA prefilter (results are identical: every reported distance is re-evaluated in the
+ * canonical fp32 arithmetic): AUTO = bf16 MFMA from d >= 24, else fp32 MFMA */
+#define HM_PREFILTER_AUTO 0
+#define HM_PREFILTER_F32  1
+#define HM_PREFILTER_BF16 2
 
 typedef struct hm_engine hm_engine;
 
@@ -54,8 +60,11 @@ const char* hm_last_error(const hm_engine* e);          /* e may be NULL: last g
  * Replaces: the pre-allocated table of HyperbolicTokenizer.__init__ (hyperbolic_merge.py:144-153)
  * as far as the search kernels are concerned, and the FAISS index objects
  * (_init_faiss_index :593-605, _build_faiss_index fast...:195-240), which are not used at all. */
-int hm_engine_create(hm_engine** out, int device, int64_t max_rows, int d1, int sign_mode);
+int hm_engine_create(hm_engine** out, int device, int64_t max_rows, int d1, int sign_mode, int prefilter);
 int hm_engine_destroy(hm_engine* e);
+/* Change the prefilter form of a live engine (HM_PREFILTER_*).  The environment variable HM_SCAN_PRECISION
+ * ("f32" | "bf16") overrides the argument of hm_engine_create, not this call. */
+int hm_set_prefilter(hm_engine* e, int prefilter);
 
 /* (Re)build the scan image from rows [0, n_rows) of the caller's table.  Replaces nothing in the
  * reference (it re-reads self.embeddings[:n] every step, hyperbolic_merge.py:250). */
@@ -86,6 +95,16 @@ int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t row_begin, 
 int hm_pairwise_topk(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end,
                      float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count,
                      void* stream);
+
+/* K2 without the exact total: the same ordered k smallest candidates; *count is the exact number of candidates
+ * when fewer than k exist, else -1 ("at least k, not counted" -- the scan then visits only what lies below its
+ * emission cut; hm_pairwise_count delivers the number when a caller asks for it).  The reference consumes the
+ * total only in log lines (fast_hyperbolic_merge.py:521,526) and for emptiness (:529). */
+int hm_pairwise_topk_nocount(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end,
+                             float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count, void* stream);
+/* Exact number of candidates among the first n_limit rows (n_limit < 0: all live rows).  Rows are only ever
+ * appended, so this is len(candidates) of the search that ran when the table had n_limit rows. */
+int hm_pairwise_count(hm_engine* e, float c, float thr, int64_t n_limit, int64_t* count, void* stream);
 
 /* All candidates (unordered) -- the caller sorts them row-major.  At most cap triples are written;
  * *total is the exact number.  Replaces: the candidate list of _find_merge_candidates
@@ -125,6 +144,46 @@ int hm_midpoint_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, 
 int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, float c, float* X_dev, int64_t ld,
                     int64_t new_row, void* stream);
 
+/* Several merges known in advance, one launch: merge t = midpoint of image rows (I[t], J[t]) with weight W[t] ->
+ * row first_row + t of the table and of the image; a merge may read rows written by earlier merges of the batch.
+ * Replaces: the hyperbolic_merge.py:326-351 arithmetic of the ~100 merges a FastHyperbolicTokenizer performs
+ * between two refreshes (fast_hyperbolic_merge.py:546-549), all of which are known when the refresh returns. */
+int hm_merge_append_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev, int64_t count,
+                          float c, float* X_dev, int64_t ld, int64_t first_row, void* stream);
+/* Forget image rows >= n_rows (undo rows appended ahead of time). */
+int hm_truncate(hm_engine* e, int64_t n_rows, void* stream);
+
+/* ---- device-resident merge loops ------------------------------------------------------------------------
+ * Token lengths len(vocab[r]) for rows [0, n): the only thing a merge needs from the token strings
+ * (w = len(tj) / (len(ti) + len(tj)), hyperbolic_merge.py:317-323).  Host array; kept on the device and
+ * extended by the loops below (len[new] = len[i] + len[j]). */
+int hm_set_token_lengths(hm_engine* e, const int32_t* lens_host, int64_t n, void* stream);
+/* `steps` (<= 64) iterations of HyperbolicTokenizer.optimize_merges (hyperbolic_merge.py:371-399: full search,
+ * sort, [0], merge) enqueued back to back -- pair scan + one tail kernel per step, no host round trip -- and read
+ * back with one synchronisation.  rec_out[4 * k] = {found, bits(d), i, j} of step k: found 1 = merged (i, j) into
+ * row n + k; 0 = no candidate (the loop ends, hyperbolic_merge.py:373-375); 2 = emission overflow at this step (run it
+ * through hm_pairwise_argmin + hm_merge_append); 3 = skipped after a 0 / 2.  *done = leading merged steps. */
+int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev, int64_t ld, int64_t steps, uint32_t* rec_out,
+                       int64_t* done, void* stream);
+/* The same merges with the nearest pair maintained as a running minimum (rows are only appended):
+ * one launch per step (merge + new row vs all rows + fold).  best_io = {found, bits(d), i, j}: in: the nearest
+ * pair of the current table (from hm_pairwise_argmin); out: the running minimum after the last executed step. */
+int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_dev, int64_t ld, int64_t steps, uint32_t* best_io,
+                        uint32_t* rec_out, int64_t* done, void* stream);
+
+/* ---- enhanced tokenizer (BASELINE config 5) ---------------------------------------------------------------
+ * Semantic-coherence distances: for candidate t the simulated merged embedding
+ * m = exp_map(x_I[t], W[t] * log_map(x_I[t], x_J[t])) -- NOT projected -- and out_dev[t * ns + s] =
+ * distance(m, x_S[t * ns + s]).  Sampling, the skip of s in {i, j}, mean and sigmoid stay with the caller.
+ * Replaces: the loop of tokenizer/enhanced_fast_hyperbolic_merge.py:308-333 (one midpoint + <= 50
+ * distance().item() calls per candidate). */
+int hm_coherence_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev, const int32_t* S_dev,
+                       int64_t b, int ns, float c, float* out_dev, void* stream);
+/* project_to_hyperboloid over rows [0, n_rows) of the caller's table IN PLACE (only column 0 changes) and the
+ * matching refresh of the engine's images and norm bounds for the live rows.  n_rows >= live rows.
+ * Replaces: _project_embeddings (enhanced_fast_hyperbolic_merge.py:784-792) and the constructor's :243-244. */
+int hm_project_table(hm_engine* e, float* X_dev, int64_t ld, int64_t n_rows, float c, void* stream);
+
 /* Dense distance block between two arbitrary device arrays: out_dev[n1, n2].
  * Replaces: batch_distance / batch_distance_optimized (embedding/lorentz_model.py:141-210) and
  * _compute_pairwise_distances (hyperbolic_merge.py:166-190).  Engine-independent. */
@@ -158,6 +217,10 @@ int hm_last_scan_stats(const hm_engine* e, float* scan_ms, int64_t* pairs, int64
  * passes) since engine creation or the last reset: summed event-timed kernel duration, pairs
  * covered and number of launches.  reset != 0 clears the totals after reading. */
 int hm_scan_totals(hm_engine* e, double* scan_ms, int64_t* pairs, int64_t* launches, int reset);
+
+/* Test hook: pretend the previous refresh ended on this emission cut (bits of u'); the next whole-table top-k
+ * search starts from it as given and has to notice by itself when it is too tight. */
+int hm_debug_force_cut(hm_engine* e, uint32_t cut_bits, int64_t k, float c);
 
 #ifdef __cplusplus
 }

@@ -690,6 +690,50 @@ HMO_EXPORT int64_t hmo_fast_pairwise_topk(const float* X, int64_t n, int64_t ld,
     return m;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* enhanced tokenizer (BASELINE config 5)                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* tokenizer/enhanced_fast_hyperbolic_merge.py:308-333 (_compute_semantic_coherence), the device part:
+ * for candidate t the simulated merged embedding m = exp_map(x_i, w * log_map(x_i, x_j)) -- NOT
+ * projected (:319-321) -- and the distances distance(m, x_s) to its ns sampled rows S[t*ns ..].
+ * The sampling (torch.randperm), the skip of s in {i, j} and the mean / sigmoid stay with the caller. */
+HMO_EXPORT void hmo_coherence_distances(const float* X, int64_t ld, int d1, const int32_t* I, const int32_t* J,
+                                        const float* W, const int32_t* S, int64_t b, int ns, float c, int sign_mode,
+                                        float* out)
+{
+    int64_t t;
+#pragma omp parallel for schedule(static)
+    for (t = 0; t < b; ++t) {
+        float* v = (float*)malloc(sizeof(float) * (size_t)d1 * 2);
+        float* m = v + d1;
+        const float* xi = X + (int64_t)I[t] * ld;
+        int k, s;
+        hmo_log_map(xi, X + (int64_t)J[t] * ld, d1, sign_mode, v);
+        for (k = 0; k < d1; ++k) v[k] = v[k] * W[t];
+        hmo_exp_map(xi, v, d1, m);
+        for (s = 0; s < ns; ++s)
+            out[t * ns + s] = hmo_distance(m, X + (int64_t)S[t * ns + s] * ld, d1, c, sign_mode);
+        free(v);
+    }
+}
+
+/* enhanced...:784-792 (_project_embeddings) and :243-244: project_to_hyperboloid over rows [0, n) of
+ * the table, in place (only column 0 changes). */
+HMO_EXPORT void hmo_project_table(float* X, int64_t ld, int d1, int64_t n, float c)
+{
+    int64_t t;
+#pragma omp parallel for schedule(static)
+    for (t = 0; t < n; ++t) {
+        float* x = X + t * ld;
+        float acc = 0.0f, r;
+        int k;
+        for (k = 1; k < d1; ++k) acc = fmaf(x[k], x[k], acc);
+        r = sqrtf(acc);
+        x[0] = sqrtf(1.0f + (c * r) * r);
+    }
+}
+
 HMO_EXPORT int hmo_num_threads(void)
 {
 #ifdef _OPENMP

@@ -65,6 +65,11 @@ def lib() -> C.CDLL:
         L.hmo_midpoint_batch.restype = None
         L.hmo_midpoint_batch.argtypes = [f32p, C.c_int64, C.c_int, i32p, i32p, f32p, C.c_int64, C.c_float,
                                          C.c_int, f32p]
+        L.hmo_coherence_distances.restype = None
+        L.hmo_coherence_distances.argtypes = [f32p, C.c_int64, C.c_int, i32p, i32p, f32p, i32p, C.c_int64, C.c_int,
+                                              C.c_float, C.c_int, f32p]
+        L.hmo_project_table.restype = None
+        L.hmo_project_table.argtypes = [f32p, C.c_int64, C.c_int, C.c_int64, C.c_float]
         L.hmo_pairwise_count.restype = C.c_int64
         L.hmo_pairwise_count.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_int,
                                          C.c_int64, C.c_int64]
@@ -191,6 +196,25 @@ def midpoint_batch(X, I, J, W, c: float, sign_mode: int) -> np.ndarray:
     lib().hmo_midpoint_batch(_p(X, C.c_float), X.shape[1], X.shape[1], _p(I, C.c_int32), _p(J, C.c_int32),
                              _p(W, C.c_float), I.shape[0], c, sign_mode, _p(out, C.c_float))
     return out
+
+
+def coherence_distances(X, I, J, W, S, c: float, sign_mode: int) -> np.ndarray:
+    """enhanced_fast_hyperbolic_merge.py:308-333: distances from the un-projected simulated midpoint of
+    (I[t], J[t]) to the sampled rows S[t, :].  -> [b, ns] fp32."""
+    X, I, J, W = _f32(X), _i32(I), _i32(J), _f32(W)
+    S = _i32(S).reshape(I.shape[0], -1)
+    out = np.empty(S.shape, np.float32)
+    if S.size:
+        lib().hmo_coherence_distances(_p(X, C.c_float), X.shape[1], X.shape[1], _p(I, C.c_int32), _p(J, C.c_int32),
+                                      _p(W, C.c_float), _p(S, C.c_int32), I.shape[0], S.shape[1], c, sign_mode,
+                                      _p(out, C.c_float))
+    return out
+
+
+def project_table(X: np.ndarray, n: int, c: float) -> None:
+    """enhanced...:784-792: project rows [0, n) of the fp32 C-contiguous table X in place."""
+    assert X.dtype == np.float32 and X.flags["C_CONTIGUOUS"]
+    lib().hmo_project_table(_p(X, C.c_float), X.shape[1], X.shape[1], n, c)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ Two oracle modes:
               ``embedding.lorentz_model.minkowski_dot`` negated (fixes distance/log_map) and
               ``batch_distance`` invoked as ``orig(x, -y, c)`` (it inlines its own dot product).
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [reference|lorentz|all]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [reference|lorentz|all] [all|g5]
 """
 from __future__ import annotations
 
@@ -281,11 +281,220 @@ def g_cli(mode: str) -> None:
         json.dump(res, f, indent=1, ensure_ascii=False)
 
 
+# ---------------------------------------------------------------------------------------------
+# G5: enhanced tokenizer (BASELINE config 5: frequency-aware scoring + adaptive curvature)
+# ---------------------------------------------------------------------------------------------
+def _enhanced_module():
+    """tokenizer/enhanced_fast_hyperbolic_merge.py does not import as shipped: it takes
+    poincare_to_lorentz / lorentz_to_poincare from embedding.lorentz_model, where they do not live.
+    The two names are injected from embedding.poincare_ball (neither is ever called on this path)."""
+    import embedding.poincare_ball as P
+    L.poincare_to_lorentz = P.poincare_to_lorentz
+    L.lorentz_to_poincare = P.lorentz_to_poincare
+    import tokenizer.enhanced_fast_hyperbolic_merge as EM
+    return EM
+
+
+def synthetic_pair_frequencies(vocab):
+    """Deterministic pair-frequency table over a vocabulary (the reference builds it from a corpus,
+    enhanced...:266-289): every fifth ordered pair gets a pseudo-random count.  Pure integer rule,
+    so that tests rebuild it without the reference."""
+    n = len(vocab)
+    out = {}
+    for a in range(n):
+        for b in range(n):
+            if (a * 7 + b * 13) % 5 == 0:
+                out[(vocab[a], vocab[b])] = 1 + (a * 31 + b * 17) % 997
+    return out
+
+
+def synthetic_corpus_sample(vocab, cands, seed=11, lines=6, chunks=12):
+    """Text lines in which the concatenations of some near pairs occur (so that the compression score
+    of enhanced...:849-899 is non-zero for them); stored in the fixture as data."""
+    rs = np.random.RandomState(seed)
+    n = len(vocab)
+    top = cands[:40]
+    out = []
+    for _ in range(lines):
+        parts = []
+        for _ in range(chunks):
+            if top and rs.rand() < 0.5:
+                c = top[int(rs.randint(0, len(top)))]
+                parts.append(vocab[c.token_i] + vocab[c.token_j])
+            else:
+                parts.append(vocab[int(rs.randint(0, n))])
+        out.append("".join(parts))
+    return out
+
+
+def _torch_state_hash() -> str:
+    return hashlib.sha256(torch.get_rng_state().numpy().tobytes()).hexdigest()
+
+
+G5_CONFIGS = {
+    # name: (n, d, thr, flags)
+    "freq_hier": dict(use_frequency_aware=True, use_hierarchical=True, use_adaptive_curvature=False,
+                      use_compression_aware=False),
+    "freq_comp_adapt": dict(use_frequency_aware=True, use_hierarchical=False, use_adaptive_curvature=True,
+                            use_compression_aware=True, optimize_curvature_freq=10 ** 6),
+    "freq_only": dict(use_frequency_aware=True, use_hierarchical=False, use_adaptive_curvature=False,
+                      use_compression_aware=False),
+}
+
+
+def _mk_enh(EM, X, thr, flags, max_vocab_size=None, curvature=1.0, corpus=None):
+    vocab = cjk_vocab(X.shape[0])
+    kw = dict(flags)
+    if kw.get("use_compression_aware"):
+        kw["corpus_sample"] = list(corpus or [])
+    tok = EM.EnhancedFastHyperbolicTokenizer(
+        vocab=vocab, embeddings=torch.nn.Parameter(X.clone()), curvature=curvature, merge_threshold=thr,
+        device=torch.device("cpu"), use_approximate_search=False,
+        max_vocab_size=max_vocab_size or (X.shape[0] + 64), **kw)
+    if kw.get("use_frequency_aware"):
+        tok.pair_frequencies = synthetic_pair_frequencies(vocab)
+    return tok
+
+
+def g5_enhanced(mode: str) -> None:
+    EM = _enhanced_module()
+    out, meta = {}, {}
+    lor = mode == "lorentz"
+    n, d, scale = (300, 10, 0.05) if lor else (40, 10, 0.05)
+    thr = 0.1
+    X = lorentz_table(n, d, seed=42, scale=scale)
+    out["X"] = X.numpy()
+    meta["n"], meta["d"], meta["thr"] = n, d, thr
+    seed_all(42)
+    probe = _mk_tok(FM.FastHyperbolicTokenizer, X, thr)
+    corpus = synthetic_corpus_sample(cjk_vocab(n), list(probe._find_merge_candidates_fast()[:40]))
+    meta["corpus_sample"] = corpus
+
+    # (a) _score_candidate on the first 64 candidates of the parent's refresh (enhanced...:903-990)
+    for name, flags in G5_CONFIGS.items():
+        seed_all(42)
+        tok = _mk_enh(EM, X, thr, flags, corpus=corpus)
+        base = FM.FastHyperbolicTokenizer._find_merge_candidates_fast(tok)
+        cands = list(base[:64])
+        torch.manual_seed(123)
+        scored = [tok._score_candidate(c) for c in cands]
+        out[f"score_{name}_i"] = np.array([c.token_i for c in cands], np.int32)
+        out[f"score_{name}_j"] = np.array([c.token_j for c in cands], np.int32)
+        out[f"score_{name}_d"] = np.array([c.distance for c in cands], np.float32)
+        for fld in ("frequency_score", "semantic_score", "compression_score", "morphology_score", "combined_score"):
+            out[f"score_{name}_{fld}"] = np.array([getattr(s, fld) for s in scored], np.float64)
+        meta[f"score_{name}_torch_state_after"] = _torch_state_hash()
+        meta[f"score_{name}_n_candidates"] = len(base)
+
+    # (b) candidate order of _find_merge_candidates_fast (enhanced...:992-1013): refresh, then a cache pop
+    for name in ("freq_hier", "freq_only"):
+        seed_all(42)
+        tok = _mk_enh(EM, X, thr, G5_CONFIGS[name], corpus=corpus)
+        torch.manual_seed(321)
+        first = tok._find_merge_candidates_fast()
+        second = tok._find_merge_candidates_fast()
+        for tag, lst in (("first", first), ("second", second)):
+            out[f"order_{name}_{tag}_i"] = np.array([c.token_i for c in lst], np.int32)
+            out[f"order_{name}_{tag}_j"] = np.array([c.token_j for c in lst], np.int32)
+            out[f"order_{name}_{tag}_score"] = np.array([c.combined_score for c in lst], np.float64)
+        meta[f"order_{name}_cache_len"] = len(tok.cache.candidates)
+        meta[f"order_{name}_torch_state_after"] = _torch_state_hash()
+
+    # (c) merge sequences with the curvature step never firing (enhanced...:1015-1209)
+    seqs = {
+        "freq_hier": dict(steps=12, log_every=5, phase_transition_steps={2: 4, 3: 8}),
+        "freq_comp_adapt": dict(steps=8, log_every=3),
+        "freq_only": dict(steps=12, log_every=5),
+    }
+    for name, kw in seqs.items():
+        seed_all(42)
+        tok = _mk_enh(EM, X, thr, G5_CONFIGS[name], corpus=corpus)
+        pairs = _record(tok)
+        torch.manual_seed(777)
+        tok.optimize_merges(**kw)
+        m = tok.current_vocab_size
+        out[f"seq_{name}_pairs"] = np.array(pairs, np.int32).reshape(-1, 2)
+        out[f"seq_{name}_rows"] = tok.embeddings.data[n:m].numpy().copy()
+        meta[f"seq_{name}"] = {
+            "kwargs": {k: ({str(a): b for a, b in v.items()} if isinstance(v, dict) else v) for k, v in kw.items()},
+            "threshold": tok.merge_threshold,
+            "phase": tok.current_phase,
+            "curvature": float(tok.get_curvature().item() if hasattr(tok.get_curvature(), "item") else tok.get_curvature()),
+            "training_stats": {str(k): v for k, v in getattr(tok, "training_stats", {}).items()},
+            "random_state_after": _state_hash(),
+            "torch_state_after": _torch_state_hash(),
+            "merges": [list(t) for t in tok.merge_history],
+            "cache_len": len(tok.cache.candidates),
+            "merge_pairs": [list(p) for p in getattr(tok, "merge_pairs", [])],
+        }
+        # (d) what save() writes for this trained tokenizer (enhanced...:1211-1298): the JSON documents
+        with tempfile.TemporaryDirectory() as td:
+            tok.save(td)
+            files = sorted(os.listdir(td))
+            meta[f"save_{name}_files"] = files
+            for fn in files:
+                if fn.endswith(".json"):
+                    meta[f"save_{name}_{fn}"] = json.load(open(os.path.join(td, fn)))
+            emb = torch.load(os.path.join(td, "embeddings.pt"), weights_only=True)
+            meta[f"save_{name}_embeddings_shape"] = list(emb.shape)
+
+    # (e) the adaptive-curvature step.  As shipped it raises at loss.backward() (SURVEY F8:
+    # distance() re-wraps c with torch.tensor(), which detaches the Parameter).  Under a ONE-LINE patch of
+    # distance() that keeps c attached, the reference's own loss functions, Adam step, clamp and
+    # re-projection run; their outputs pin the analytic-gradient form of the build.  This is NOT the
+    # behaviour of the reference as shipped (that is an exception) -- recorded as "patched".
+    if lor:
+        def distance_attached(x, y, c=1.0):
+            xy = -L.minkowski_dot(x, y)
+            xy = torch.clamp(xy, min=1.0 + 1e-8)
+            ct = c if isinstance(c, torch.Tensor) else torch.tensor(c, device=x.device, dtype=x.dtype)
+            return torch.acosh(xy) / torch.sqrt(ct)
+        orig = EM.distance
+        EM.distance = distance_attached
+        try:
+            seed_all(42)
+            flags = dict(use_frequency_aware=False, use_hierarchical=False, use_adaptive_curvature=True,
+                         use_compression_aware=False, optimize_curvature_freq=10 ** 6, curvature_lr=0.01)
+            tok = _mk_enh(EM, X, thr, flags, max_vocab_size=n + 40, curvature=1.0)
+            first = FM.FastHyperbolicTokenizer._find_merge_candidates_fast(tok)
+            for q in (0, 5, 10, 20, 30, 45):            # distinct pairs: no duplicated / NaN rows
+                tok._merge_tokens(first[q].token_i, first[q].token_j)
+            out["curv_rows_before"] = tok.embeddings.data.numpy().copy()
+            meta["curv_merge_pairs"] = [list(p) for p in tok.merge_pairs]
+            meta["curv_n"] = tok.current_vocab_size
+            steps_rec = []
+            torch.manual_seed(99)
+            for _ in range(3):
+                emb = tok.embeddings.detach()
+                st0 = torch.get_rng_state()
+                h = tok._compute_hierarchy_preservation_loss(emb)
+                dl = tok._compute_distortion_loss(emb)
+                torch.set_rng_state(st0)
+                tok._optimize_curvature(emb)
+                tok._project_embeddings()
+                steps_rec.append({"hierarchy_loss": float(h.item()), "distortion_loss": float(dl.item()),
+                                  "curvature_after": float(tok.curvature.item())})
+            meta["curv_steps"] = steps_rec
+            meta["curv_torch_state_after"] = _torch_state_hash()
+            out["curv_rows_after"] = tok.embeddings.data.numpy().copy()
+        finally:
+            EM.distance = orig
+
+    np.savez_compressed(os.path.join(HERE, f"g5_enhanced_{mode}.npz"), **out)
+    with open(os.path.join(HERE, f"g5_enhanced_{mode}.json"), "w") as f:
+        json.dump(meta, f, indent=1, ensure_ascii=False)
+
+
 def main() -> None:
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    only = sys.argv[2] if len(sys.argv) > 2 else "all"      # e.g. "g5": regenerate one family
     modes = ("reference", "lorentz") if which == "all" else (which,)
     for mode in modes:
         set_mode(mode)
+        if only == "g5":
+            g5_enhanced(mode)
+            print(f"[{mode}] g5 done", flush=True)
+            continue
         g1_primitives(mode)
         print(f"[{mode}] g1 done", flush=True)
         g2_candidates(mode)
@@ -294,6 +503,8 @@ def main() -> None:
         print(f"[{mode}] g3 done", flush=True)
         g_cli(mode)
         print(f"[{mode}] cli done", flush=True)
+        g5_enhanced(mode)
+        print(f"[{mode}] g5 done", flush=True)
     set_mode("reference")
 
 

@@ -42,7 +42,7 @@ class OracleEngine:
     def _range(self, row_begin, row_end):
         return max(0, row_begin), (self._n if row_end < 0 else min(row_end, self._n))
 
-    def topk(self, c, thr, k, row_begin=0, row_end=-1):
+    def topk(self, c, thr, k, row_begin=0, row_end=-1, count=True):
         self.calls["topk"] += 1
         r0, r1 = self._range(row_begin, row_end)
         thr = float(np.float32(thr))
@@ -93,6 +93,62 @@ class OracleEngine:
             if best is None or key < best:
                 best = key
         return best
+
+    # -- config 5 ---------------------------------------------------------------------------------
+    def coherence_distances(self, I, J, W, S, c):
+        return O.coherence_distances(self.X, I, J, W, S, float(c), self.sign_mode)
+
+    def project_table(self, table, n_rows, c):
+        t = table.detach()
+        X = np.ascontiguousarray(t.cpu().numpy()[:n_rows], np.float32)
+        O.project_table(X, n_rows, float(c))
+        t[:n_rows] = torch.from_numpy(X)
+        self.X[:self._n] = X[:self._n]
+
+    def rows_pair_distance(self, table, A, B, c):
+        T = table.detach().cpu().numpy()
+        return O.distance(T[np.asarray(A, np.int64)], T[np.asarray(B, np.int64)], float(c), self.sign_mode)
+
+    # -- device-resident loops (same record format as MergeEngine) ---------------------------------
+    def set_token_lengths(self, lengths):
+        self.lens = list(int(v) for v in lengths)
+
+    def std_merge_steps(self, c, thr, table, steps):
+        recs, done, alive = [], 0, True
+        for _ in range(steps):
+            if not alive:
+                recs.append((3, 0.0, -1, -1))
+                continue
+            hit = self.argmin(c, thr)
+            if hit is None:
+                recs.append((0, 0.0, -1, -1))
+                alive = False
+                continue
+            d, i, j = hit
+            li, lj = self.lens[i], self.lens[j]
+            self.merge_append(i, j, lj / (li + lj), c, table, self._n)
+            self.lens.append(li + lj)
+            recs.append((1, d, i, j))
+            done += 1
+        return recs, done
+
+    def incr_merge_steps(self, c, thr, table, steps, best):
+        recs, done = [], 0
+        for _ in range(steps):
+            if best is None:
+                recs.append((0, 0.0, -1, -1) if len([r for r in recs if r[0] != 1]) == 0 else (3, 0.0, -1, -1))
+                continue
+            d, i, j = best
+            li, lj = self.lens[i], self.lens[j]
+            row = self._n
+            self.merge_append(i, j, lj / (li + lj), c, table, row)
+            self.lens.append(li + lj)
+            recs.append((1, d, i, j))
+            done += 1
+            cand = self.row_argmin(row, row, c, thr)
+            if cand is not None and cand < best:
+                best = cand
+        return recs, done, best
 
     def scan_stats(self):
         return {"scan_ms": 0.0, "pairs": 0, "emitted": 0, "passes": 0}

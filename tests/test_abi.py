@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.load()
     for name in _header_functions():
         assert hasattr(L, name), name
-    assert L.hm_abi_version() == 1
+    assert L.hm_abi_version() == 2
 
 
 def test_engine_creation_fails_loudly_without_gpu():
@@ -36,7 +36,7 @@ def test_engine_creation_fails_loudly_without_gpu():
     from hyptokenizer_amd.engine import HypMergeUnavailable, MergeEngine
     L = _lib.load()
     h = C.c_void_p(0)
-    st = L.hm_engine_create(C.byref(h), 0, 1000, 11, 1)
+    st = L.hm_engine_create(C.byref(h), 0, 1000, 11, 1, 0)
     assert st != 0 and not h.value
     assert b"no HIP device" in L.hm_last_error(None) or st > 0
     with pytest.raises(HypMergeUnavailable):
@@ -47,11 +47,12 @@ def test_argument_errors_are_reported():
     from hyptokenizer_amd import _lib
     L = _lib.load()
     h = C.c_void_p(0)
-    assert L.hm_engine_create(None, 0, 1000, 11, 1) == _lib.HM_E_ARG
-    assert L.hm_engine_create(C.byref(h), 0, 1000, 1, 1) == _lib.HM_E_ARG          # d1 < 2
-    assert L.hm_engine_create(C.byref(h), 0, 1000, 400, 1) == _lib.HM_E_ARG        # d1 > 129
-    assert L.hm_engine_create(C.byref(h), 0, 10 ** 7, 11, 1) == _lib.HM_E_ARG      # rows > 131072
-    assert L.hm_engine_create(C.byref(h), 0, 1000, 11, 7) == _lib.HM_E_ARG         # sign mode
+    assert L.hm_engine_create(None, 0, 1000, 11, 1, 0) == _lib.HM_E_ARG
+    assert L.hm_engine_create(C.byref(h), 0, 1000, 1, 1, 0) == _lib.HM_E_ARG          # d1 < 2
+    assert L.hm_engine_create(C.byref(h), 0, 1000, 400, 1, 0) == _lib.HM_E_ARG        # d1 > 129
+    assert L.hm_engine_create(C.byref(h), 0, 10 ** 7, 11, 1, 0) == _lib.HM_E_ARG      # rows > 131072
+    assert L.hm_engine_create(C.byref(h), 0, 1000, 11, 7, 0) == _lib.HM_E_ARG      # sign mode
+    assert L.hm_engine_create(C.byref(h), 0, 1000, 11, 1, 9) == _lib.HM_E_ARG      # prefilter form
     assert L.hm_set_table(None, None, 11, 5, None) == _lib.HM_E_ARG
     assert L.hm_rows(None) == -1
     assert L.hm_last_error(None)
