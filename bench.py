@@ -8,24 +8,29 @@
 A "step" is ONE merge iteration of ``HyperbolicTokenizer.optimize_merges`` (reference
 ``tokenizer/hyperbolic_merge.py:357-412``): a full all-pairs Lorentz-distance search for the
 nearest pair below the threshold, then the log-map/exp-map midpoint appended as a new row.
-Workload: V = 50 000 synthetic Lorentz rows, d = 100, fp32, curvature 1, sign-corrected Minkowski
-form ("lorentz": the mode in which the search is non-degenerate), threshold 0.5.
-Inputs are resident in HBM before the timed region.  With N > 1 ranks the rows of the pair
-triangle are sharded over the ranks (equal pair counts), each rank scans its share of the SAME
+Headline workload (BASELINE configs[2], the one the metric is quoted on): V = 50 000 synthetic Lorentz
+rows, d = 100, fp32 table, curvature 1, sign-corrected Minkowski form ("lorentz": the mode in which the
+search is non-degenerate), threshold 0.5, bf16-MFMA prefilter + canonical fp32
+re-evaluation.  Inputs are resident in HBM before the timed region.  With N > 1 ranks the rows of the
+pair triangle are sharded over the ranks (equal pair counts), each rank scans its share of the SAME
 problem (strong scaling), the best records are all-gathered over RCCL and every rank applies the
 merge to its replica.
 
-One JSON line on rank 0; see README/DESIGN.md for the fields.  `roofline` is for the dominant
-kernel of the timed run (hm_scan_kernel; by default its bf16-MFMA prefilter form, survivors are
-re-evaluated in the canonical fp32 arithmetic): achieved = N(N-1)(d+1) flops per launch (triangle
-only; the reference's dense convention would be 2x) / the launch duration measured with HIP events
-on the launch stream inside the timed region.  `roofline_fp32_form` is the same search with the
-exact fp32-MFMA prefilter (HM_SCAN_PRECISION=f32), timed right after on the same table.  `cpu_baseline` times the oracle's OpenMP restatement of
-the same search on a bounded row sample on this host's cores (rank 0, N = 1 only).
+One JSON line on rank 0.  `roofline` is for the dominant kernel of the timed run (hm_scan_kernel):
+achieved = N(N-1)(d+1) algorithmic flops per launch (triangle only; the reference's dense convention
+would be 2x) / the launch duration measured with HIP events on the launch stream inside the timed
+region.  `legs` holds the other BASELINE configurations measured the same way on this GPU (N = 1 only):
+V = 100 000 d = 100 (the north star's target size), V = 50 000 d = 50 with the exact fp32-MFMA prefilter
+(config 2), the literal sign mode (the classes' default), and config 5 (enhanced tokenizer: frequency-aware
+scoring + adaptive curvature).  `roofline_bw` lists the bandwidth-bound kernels of the path (one-row-vs-all,
+merge, gathered distances, coherence, table re-projection): algorithmic bytes per launch / event time / 8 TB/s.
+`cpu_baseline` times the oracle's OpenMP restatement of the same search on a bounded row sample on this host's
+cores (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import gc
 import json
 import os
@@ -43,6 +48,7 @@ import torch.distributed as dist  # noqa: E402
 V, D, SCALE, SEED, THR, CURV = 50000, 100, 0.05, 42, 0.5, 1.0
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparsity figure)
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E
 
 
 def cpu_baseline(X: np.ndarray, device, budget_s: float = 12.0) -> dict:
@@ -76,19 +82,19 @@ def cpu_baseline(X: np.ndarray, device, budget_s: float = 12.0) -> dict:
     g = gpu_engine.argmin(CURV, THR, 0, rows)
     same = (g is None and oc == 0) or (g is not None and oc > 0 and (g[1], g[2]) == (int(oi[0]), int(oj[0]))
                                        and np.float32(g[0]).view(np.uint32) == od[:1].view(np.uint32)[0])
+    del gpu_engine, table
     return {
         "value": 1.0 / est_scan_s, "unit": "merges/s", "cores": cores, "kind": "port",
         "sample": f"rows [0,{rows}) of the V={n} d={D} search = {100 * frac:.1f}% of all pairs in {t:.2f} s, "
                   f"extrapolated by pair count (midpoint cost negligible)",
         "gflops": 2.0 * pairs(rows) * (D + 1) / t / 1e9,
         "same_pair_as_gpu_on_sample": bool(same),
+        "note": "the oracle's own OpenMP restatement (the reference cannot run at this size, SURVEY F9): context, not a target",
     }
 
 
 def traffic_from_profiles(form: str):
-    """Fabric-side bytes per scan launch from the committed PMC pass (profiles/*_pmc_scan_kernel.json:
-    FETCH_SIZE x 1024 x 2 on gfx950 + WRITE_SIZE x 1024, MI355X_MICROARCH.md HBM section).  PMC
-    counters cannot be collected from inside the timed run; same kernel, same size."""
+    """Fabric-side bytes per scan launch from the committed PMC pass (profiles/*_pmc_scan_kernel_<form>.json)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_scan_kernel_{form}.json")))
     if not files:
@@ -101,12 +107,173 @@ def traffic_from_profiles(form: str):
         return None, None
 
 
+def warm_clocks(eng, ms: float = 60.0) -> None:
+    """>= `ms` of back-to-back scans before a timed region: a 20-step run must measure the steady state"""
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        eng.argmin(CURV, THR)
+    torch.cuda.synchronize()
+
+
+def std_loop_leg(vocab_size, dim, prefilter, sign, steps, device, thr=THR, label=""):
+    """merges/s of the standard loop + the scan's roofline for another configuration (N = 1)"""
+    from hyptokenizer_amd.synthetic import cjk_vocab, lorentz_table
+    from hyptokenizer_amd.tokenizer.hyperbolic_merge import HyperbolicTokenizer
+    X = lorentz_table(vocab_size, dim, seed=SEED, scale=SCALE)
+    tok = HyperbolicTokenizer(cjk_vocab(vocab_size), torch.nn.Parameter(X), curvature=CURV, merge_threshold=thr, device=device,
+                              max_vocab_size=vocab_size + steps + 80, sign_convention=sign, prefilter=prefilter)
+    eng = tok._get_engine()
+    tok.optimize_merges(steps=8, log_every=10 ** 9)
+    eng.scan_totals(reset=True)
+    gc.collect()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tok.optimize_merges(steps=steps, log_every=10 ** 9)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    done = len(tok.merge_history) - 8
+    tot = eng.scan_totals()
+    out = {"workload": label, "merges_per_s": done / el if el > 0 else None, "ms_per_step": 1e3 * el / max(done, 1), "steps": done}
+    if tot["launches"] > 0 and tot["scan_ms"] > 0:
+        ms = tot["scan_ms"] / tot["launches"]
+        fl = 2.0 * (dim + 1) * tot["pairs"] / tot["launches"]
+        bf = prefilter != "f32" and dim >= 24
+        peak = PEAK_BF16_MFMA_TFLOPS if bf else PEAK_FP32_MFMA_TFLOPS
+        out["roofline"] = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                           "frac": fl / (ms * 1e-3) / 1e12 / peak, "avg_launch_ms": ms, "timed_launches": tot["launches"],
+                           "form": "bf16" if bf else "f32"}
+    del tok, eng
+    return out
+
+
+def bandwidth_kernels(device) -> list:
+    """Event-timed bandwidth-bound kernels of the path at V = 50 000, d = 100: algorithmic bytes
+    per launch / average duration of back-to-back launches on the launch stream / 8 TB/s."""
+    from hyptokenizer_amd import _lib
+    from hyptokenizer_amd.engine import MergeEngine
+    from hyptokenizer_amd.synthetic import lorentz_table
+    L = _lib.load()
+    n, d1 = V, D + 1
+    X = lorentz_table(n, D, seed=SEED, scale=SCALE)
+    table = torch.zeros((n + 2048, d1), device=device)
+    table[:n] = X.to(device)
+    eng = MergeEngine(n + 2048, d1, "lorentz", device)
+    eng.set_table(table, n)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    rs_bytes = 4 * (4 * 25 + 8)                      # fp32 image row (NG = 25, odd chunk count): 432 B
+    out = []
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3     # s per launch
+
+    def rec(name, nbytes, secs, note):
+        gbps = nbytes / secs / 1e9
+        out.append({"kernel": name, "bytes_per_launch": nbytes, "avg_launch_us": secs * 1e6, "achieved": gbps,
+                    "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "bound": "hbm", "note": note})
+
+    # gathered pair distances (K5): two image rows read per output
+    b = 200000
+    I = torch.randint(0, n, (b,), dtype=torch.int32, device=device)
+    J = torch.randint(0, n, (b,), dtype=torch.int32, device=device)
+    o = torch.empty(b, device=device)
+    s = timed(lambda: L.hm_pair_distance(eng._h, C.c_void_p(I.data_ptr()), C.c_void_p(J.data_ptr()), b, C.c_float(CURV),
+                                         C.c_void_p(o.data_ptr()), stream), 20)
+    rec("hm_pairdist_kernel", b * (2 * rs_bytes + 12), s, f"{b} gathered pairs, 2 x 432 B rows each (random rows: cache-resident image)")
+    # one row vs all (K3): the whole image once
+    o2 = torch.empty(n, device=device)
+    s = timed(lambda: L.hm_row_vs_all(eng._h, n - 1, n, C.c_float(CURV), C.c_void_p(o2.data_ptr()), stream), 50)
+    rec("hm_rowvsall_kernel", n * (rs_bytes + 4), s, "row n-1 against all rows: the fp32 image once + n distances")
+    # coherence (config 5): per candidate 2 rows + 50 sampled rows read, 50 distances written
+    bc, ns = 10000, 50
+    Ic, Jc = I[:bc].contiguous(), J[:bc].contiguous()
+    W = torch.full((bc,), 0.5, device=device)
+    S = torch.randint(0, n, (bc, ns), dtype=torch.int32, device=device)
+    oc = torch.empty((bc, ns), device=device)
+    s = timed(lambda: L.hm_coherence_batch(eng._h, C.c_void_p(Ic.data_ptr()), C.c_void_p(Jc.data_ptr()), C.c_void_p(W.data_ptr()),
+                                           C.c_void_p(S.data_ptr()), bc, ns, C.c_float(CURV), C.c_void_p(oc.data_ptr()), stream), 20)
+    rec("hm_coherence_kernel", bc * ((ns + 2) * rs_bytes + ns * 8), s, f"{bc} candidates x {ns} sampled rows (config 5 refresh)")
+    # table re-projection (K6): spatial part of every table row read, x0 written (+ image time slots)
+    s = timed(lambda: L.hm_project_table(eng._h, C.c_void_p(table.data_ptr()), table.stride(0), n, C.c_float(CURV), stream), 50)
+    rec("hm_project_table_kernel", n * (4 * D + 4 + 4 + 12), s, "rows [0, n): d spatial floats read, x0 written to the table and both images")
+    # incremental step (merge + new row vs all + fold), from the device-resident loop
+    eng.set_table(table, n)
+    eng.set_token_lengths(np.ones(n, np.int32))
+    best = eng.argmin(CURV, THR)
+    if best is not None:
+        eng.incr_merge_steps(CURV, THR, table, 8, best)
+        best = eng.argmin(CURV, THR)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done_total = 0
+        for _ in range(8):
+            _r, done, best = eng.incr_merge_steps(CURV, THR, table, 64, best)
+            done_total += done
+        torch.cuda.synchronize()
+        s = (time.perf_counter() - t0) / max(done_total, 1)
+        rec("hm_incr_step_kernel", (n + done_total / 2) * rs_bytes, s,
+            "one launch per merge: midpoint + new row vs all rows + fold; wall time of 64-step batches / steps (host sync per batch included)")
+    del eng
+    return out
+
+
+def config5_leg(device, steps: int = 24) -> dict:
+    """BASELINE config 5 on one GPU: EnhancedFastHyperbolicTokenizer, frequency-aware scoring + adaptive curvature
+    (V = 100 000, d = 100).  Per step: 100 cached candidates scored (torch.randperm(n) per candidate on the host, as the
+    reference draws them; midpoint + 50 gathered distances per candidate in one fused kernel); one refresh scores every
+    candidate; the curvature step fires once (analytic gradient; the reference's raises)."""
+    import random
+    from hyptokenizer_amd.synthetic import cjk_vocab, lorentz_table
+    from hyptokenizer_amd.tokenizer.enhanced_fast_hyperbolic_merge import EnhancedFastHyperbolicTokenizer
+    n5, d5 = 100000, 100
+    X = lorentz_table(n5, d5, seed=SEED, scale=SCALE)
+    vocab = cjk_vocab(n5)
+    random.seed(SEED)
+    torch.manual_seed(SEED)
+    tok = EnhancedFastHyperbolicTokenizer(vocab, torch.nn.Parameter(X), curvature=CURV, merge_threshold=0.45, device=device,
+                                          max_vocab_size=n5 + 64, sign_convention="lorentz", use_frequency_aware=True,
+                                          use_hierarchical=False, use_adaptive_curvature=True, use_compression_aware=False,
+                                          optimize_curvature_freq=steps // 2)
+    rs = np.random.RandomState(SEED)                  # synthetic pair-frequency table: Zipf(1.2) counts over random pairs
+    a, b = rs.randint(0, n5, 200000), rs.randint(0, n5, 200000)
+    cnt = rs.zipf(1.2, 200000).clip(max=10 ** 6)
+    tok.pair_frequencies = {(vocab[i], vocab[j]): int(c) for i, j, c in zip(a.tolist(), b.tolist(), cnt.tolist())}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tok.optimize_merges(steps=steps, log_every=10 ** 9, adaptive_threshold=False)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    done = len(tok.merge_history)
+    # where the time goes: the host RNG that the reference semantics prescribe
+    t1 = time.perf_counter()
+    for _ in range(20):
+        torch.randperm(n5)
+    rp = (time.perf_counter() - t1) / 20
+    return {"workload": f"EnhancedFastHyperbolicTokenizer.optimize_merges V={n5} d={d5} lorentz thr=0.45 freq-aware + adaptive "
+                        f"curvature (one curvature step + whole-table re-projection inside the run)",
+            "merges_per_s": done / el, "ms_per_step": 1e3 * el / max(done, 1), "steps": done,
+            "curvature_after": float(tok.get_curvature()),
+            "host_randperm_ms": rp * 1e3,
+            "note": "dominated by torch.randperm(n) on the host, once per scored candidate (reference semantics: "
+                    "enhanced_fast_hyperbolic_merge.py:324-325); the reference itself needs ~2.5 ms of distance() calls per "
+                    "candidate on top of that and cannot run its all-pairs search at this size (SURVEY F9)"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="headline line only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,6 +315,8 @@ def main() -> None:
         torch.cuda.synchronize()
 
     tok.optimize_merges(steps=args.warmup, log_every=10 ** 9)
+    if world == 1:
+        warm_clocks(eng)                         # >= 60 ms of scans whatever --warmup says
     eng.scan_totals(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -170,22 +339,23 @@ def main() -> None:
     # fast-path figure (FastHyperbolicTokenizer semantics: one exact top-10000 search per ~101 steps)
     fast = None
     if rank == 0 or world > 1:
-        fsteps = 1010
+        fsteps = 2020
         ftok = FastHyperbolicTokenizer(vocab, torch.nn.Parameter(X), curvature=CURV, merge_threshold=THR, device=device,
                                        max_vocab_size=V + fsteps + 64, sign_convention="lorentz", shard=shard)
         ftok._get_engine()
-        ftok.optimize_merges(steps=101, log_every=10 ** 9, adaptive_threshold=False)
+        ftok.optimize_merges(steps=202, log_every=10 ** 9, adaptive_threshold=False)
         barrier()
         tf0 = time.perf_counter()
-        ftok.optimize_merges(steps=fsteps - 101, log_every=10 ** 9, adaptive_threshold=False)
+        ftok.optimize_merges(steps=fsteps - 202, log_every=10 ** 9, adaptive_threshold=False)
         barrier()
         tf = time.perf_counter() - tf0
-        fast = {"merges_per_s": (len(ftok.merge_history) - 101) / tf, "steps": fsteps - 101,
-                "note": "FastHyperbolicTokenizer.optimize_merges: cache of 10000, one exact top-k search per ~101 steps"}
+        fast = {"merges_per_s": (len(ftok.merge_history) - 202) / tf, "steps": fsteps - 202,
+                "note": "FastHyperbolicTokenizer.optimize_merges: cache of 10000, one exact top-k search per ~101 steps; "
+                        "the merges between two refreshes are issued as one launch"}
+        del ftok
 
     # incremental figure (SURVEY 8(d) variant (ii)): same merges, nearest pair maintained with one
-    # row-vs-all pass per step instead of a full search; the merge sequence is checked against the
-    # timed run's
+    # row-vs-all pass per step instead of a full search; the merge sequence is checked against the timed run's
     incr = None
     if rank == 0 or world > 1:
         isteps = max(args.steps + args.warmup, 2)
@@ -200,31 +370,34 @@ def main() -> None:
         ti = time.perf_counter() - ti0
         incr = {"merges_per_s": (len(itok.merge_history) - 1) / ti, "steps": isteps - 1,
                 "same_merges_as_full_search": itok.merge_history == tok.merge_history[:len(itok.merge_history)],
-                "note": "HyperbolicTokenizer(incremental=True): one full search, then one row-vs-all reduction per merge"}
+                "note": "HyperbolicTokenizer(incremental=True): one full search, then one launch per merge "
+                        "(midpoint + new row vs all + fold), 64 steps per host call"}
+        del itok
 
-    fp32_form = None
-    if rank == 0 and world == 1 and os.environ.get("HM_SCAN_PRECISION", "auto") != "f32":
-        from hyptokenizer_amd.engine import MergeEngine
-        os.environ["HM_SCAN_PRECISION"] = "f32"
+    legs, bw = None, None
+    if rank == 0 and world == 1 and not args.no_legs:
+        legs = {}
+        lsteps = max(20, min(args.steps, 100))
+        for key, fn in (
+            ("v100k_d100_bf16", lambda: std_loop_leg(100000, 100, "bf16", "lorentz", lsteps, device,
+                                                     label="V=100000 d=100 lorentz thr=0.5, bf16 prefilter (north star target size)")),
+            ("v50k_d50_f32", lambda: std_loop_leg(50000, 50, "f32", "lorentz", lsteps, device,
+                                                  label="V=50000 d=50 lorentz thr=0.5, fp32-MFMA prefilter (BASELINE config 2)")),
+            ("v50k_d100_f32", lambda: std_loop_leg(50000, 100, "f32", "lorentz", 20, device,
+                                                   label="V=50000 d=100 lorentz thr=0.5, fp32-MFMA prefilter")),
+            ("v50k_d100_literal", lambda: std_loop_leg(50000, 100, "auto", "reference", 20, device, thr=0.1,
+                                                       label="V=50000 d=100 literal sign (the classes' default: every pair at distance 0, tie flood) thr=0.1")),
+            ("config5_enhanced", lambda: config5_leg(device)),
+        ):
+            try:
+                legs[key] = fn()
+            except Exception as exc:             # a leg must not take the headline line down with it
+                legs[key] = {"error": f"{type(exc).__name__}: {exc}"}
+            barrier()
         try:
-            e32 = MergeEngine(V + 8, D + 1, "lorentz", device)
-            t32 = torch.zeros((V + 8, D + 1), dtype=torch.float32, device=device)
-            t32[:V] = X.to(device)
-            e32.set_table(t32, V)
-            for _ in range(3):
-                e32.argmin(CURV, THR)
-            e32.scan_totals(reset=True)
-            for _ in range(20):
-                r32 = e32.argmin(CURV, THR)
-            tt = e32.scan_totals()
-            ms32 = tt["scan_ms"] / tt["launches"]
-            fl32 = 2.0 * (D + 1) * tt["pairs"] / tt["launches"]
-            fp32_form = {"bound": "mfma", "achieved": fl32 / (ms32 * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": fl32 / (ms32 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "kernel": "hm_scan_kernel<NG=25,lorentz,ARGMIN,fp32>", "avg_launch_ms": ms32, "launches": tt["launches"],
-                         "nearest_pair": list(r32) if r32 else None}
-        finally:
-            os.environ.pop("HM_SCAN_PRECISION", None)
+            bw = bandwidth_kernels(device)
+        except Exception as exc:
+            bw = [{"error": f"{type(exc).__name__}: {exc}"}]
 
     if rank == 0:
         launches = sum(p[2] for p in per_rank)
@@ -249,23 +422,26 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16 prefilter + f32 canonical" if os.environ.get("HM_SCAN_PRECISION", "auto") != "f32" else "f32",
+            "dtype": "bf16 prefilter + f32 canonical" if bf16 else "f32",
             "data": "synthetic",
             "config": {"workload": f"HyperbolicTokenizer.optimize_merges, full all-pairs search every step, V={V} d={D} "
                                    f"fp32, lorentz sign, thr={THR}, c={CURV}, scale={SCALE}, seed={SEED}",
                        "vocab": V, "dim": D, "merge_threshold": THR, "parallelism": f"rows sharded over {world} rank(s)"},
             "pairwise_dist_GBps_effective": (n_mid * n_mid * 4.0) / (scan_ms_per_step * 1e-3) / 1e9,
+            "step_overhead_ms": 1e3 * elapsed / max(args.steps, 1) - avg_ms,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": ("bytes per launch past the XCD L2s (FETCH_SIZE corrected x2 + WRITE_SIZE) from "
                                           f"profiles/{traffic_src}; served by the Infinity Cache (the scan image is "
                                           "resident), compulsory bytes = the image once") if traffic else None,
                          "kernel": kernel_name, "avg_launch_ms": avg_ms,
-                         "flops_per_launch": flops_per_launch, "launches": launches,
-                         "note": "flops = N(N-1)(d+1) algorithmic (triangle); peak = dense MFMA peak of the prefilter's dtype"},
-            "roofline_fp32_form": fp32_form,
+                         "flops_per_launch": flops_per_launch, "timed_launches": launches,
+                         "note": "flops = N(N-1)(d+1) algorithmic (triangle); peak = dense MFMA peak of the prefilter's dtype; "
+                                 "one scan launch per 64-step device batch carries the HIP events"},
             "fast_path": fast,
             "incremental": incr,
+            "legs": legs,
+            "roofline_bw": bw,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X.numpy(), device)

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "hm_rows_minkowski", "hm_rows_distance", "hm_rows_log_map", "hm_rows_exp_map", "hm_rows_project",
     "hm_last_scan_stats", "hm_scan_totals", "hm_set_prefilter", "hm_pairwise_topk_nocount", "hm_pairwise_count",
     "hm_merge_append_batch", "hm_truncate", "hm_set_token_lengths", "hm_std_merge_steps", "hm_incr_merge_steps",
-    "hm_coherence_batch", "hm_project_table", "hm_debug_force_cut",
+    "hm_coherence_batch", "hm_project_table", "hm_debug_force_cut", "hm_randperm_prefix",
 )
 
 
@@ -83,6 +83,7 @@ def load() -> C.CDLL:
     L.hm_coherence_batch.argtypes = [vp, vp, vp, vp, vp, i64, C.c_int, f32, vp, vp]
     L.hm_project_table.argtypes = [vp, vp, i64, i64, f32, vp]
     L.hm_debug_force_cut.argtypes = [vp, C.c_uint32, i64, f32]
+    L.hm_randperm_prefix.argtypes = [vp, pi32, C.POINTER(C.c_uint32), i64, i32, i64, vp]
     L.hm_engine_destroy.argtypes = [vp]
     L.hm_set_table.argtypes = [vp, vp, i64, i64, vp]
     L.hm_update_rows.argtypes = [vp, vp, i64, i64, i64, vp]

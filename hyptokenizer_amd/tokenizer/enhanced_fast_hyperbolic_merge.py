@@ -78,6 +78,42 @@ class EnhancedMergeCandidate(MergeCandidate):
         return self.combined_score < other.combined_score
 
 
+def randperm_prefixes(n: int, ns: int, count: int) -> np.ndarray:
+    """``[torch.randperm(n)[:ns] for _ in range(count)]`` as an int32 ``[count, ns]`` array, consuming torch's
+    CPU generator exactly as those calls do.  Served by the library's host helper ``hm_randperm_prefix`` (the
+    generator's MT19937 state is read from and written back to ``torch.get/set_rng_state``); plain
+    ``torch.randperm`` calls when that is not possible (n >= 2^32 / 20, an unexpected state layout)."""
+    out = np.empty((count, ns), np.int32)
+    if count == 0 or ns == 0:
+        for _ in range(count):
+            torch.randperm(n)
+        return out
+    st = torch.get_rng_state()
+    if st.numel() == 5056 and n < (2 ** 32 - 1) // 20 and ns <= 4096:
+        from .. import _lib
+        import ctypes as C
+        raw = st.numpy().copy()
+        # CPUGeneratorImplStateLegacy: u64 seed | i32 left | i32 seeded | u64 next | u64 state[624] | ...
+        left = raw[8:12].view(np.int32)
+        seeded = raw[12:16].view(np.int32)
+        nxt = raw[16:24].view(np.uint64)
+        words = raw[24:24 + 624 * 8].view(np.uint64)
+        if seeded[0] == 1 and 1 <= left[0] <= 624:
+            mt = words.astype(np.uint32)
+            c_left, c_next = C.c_int32(int(left[0])), C.c_uint32(int(nxt[0]))
+            rc = _lib.load().hm_randperm_prefix(C.c_void_p(mt.ctypes.data), C.byref(c_left), C.byref(c_next), int(n), int(ns),
+                                                int(count), C.c_void_p(out.ctypes.data))
+            if rc == 0:
+                words[:] = mt
+                left[0] = c_left.value
+                nxt[0] = c_next.value
+                torch.set_rng_state(torch.from_numpy(raw))
+                return out
+    for t in range(count):
+        out[t] = torch.randperm(n)[:ns].numpy()
+    return out
+
+
 def _row_means(dist: np.ndarray, keep: np.ndarray) -> np.ndarray:
     """``np.mean`` of the kept entries of every row in float64 -- the value ``np.mean(list_of_floats)``
     gives the reference (``:340``), same summation order: full rows go through one reduction over the
@@ -236,11 +272,7 @@ class EnhancedFastHyperbolicTokenizer(FastHyperbolicTokenizer):
         """``torch.randperm(n)[:50]`` once per candidate, in candidate order (reference ``:324-325``:
         the torch CPU generator is consumed exactly as there)."""
         n = self.current_vocab_size
-        ns = min(COHERENCE_SAMPLES, n)
-        out = np.empty((count, ns), np.int32)
-        for t in range(count):
-            out[t] = torch.randperm(n)[:ns].numpy()
-        return out
+        return randperm_prefixes(n, min(COHERENCE_SAMPLES, n), count)
 
     def _semantic_coherence_batch(self, ii: np.ndarray, jj: np.ndarray) -> np.ndarray:
         """Reference ``_compute_semantic_coherence`` (``:291-346``) for a list of candidates: the RNG

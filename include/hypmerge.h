@@ -184,6 +184,13 @@ int hm_coherence_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev,
  * Replaces: _project_embeddings (enhanced_fast_hyperbolic_merge.py:784-792) and the constructor's :243-244. */
 int hm_project_table(hm_engine* e, float* X_dev, int64_t ld, int64_t n_rows, float c, void* stream);
 
+/* Host-only helper (no GPU work): out[t * ns + q] = torch.randperm(n)[q] for t = 0..count-1 and q < ns, drawn from
+ * the MT19937 state of torch's CPU generator -- mt_state[624] words, *left, *next as in at::mt19937 -- which is
+ * advanced exactly as `count` calls of torch.randperm(n) would advance it (n < 2^32 / 20, ns <= 4096).
+ * Replaces: torch.randperm(current_vocab_size)[:sample_size] per scored candidate
+ * (enhanced_fast_hyperbolic_merge.py:324-325): O(n) draws of the recurrence instead of an O(n) random-access shuffle. */
+int hm_randperm_prefix(uint32_t* mt_state, int32_t* left, uint32_t* next, int64_t n, int32_t ns, int64_t count, int32_t* out);
+
 /* Dense distance block between two arbitrary device arrays: out_dev[n1, n2].
  * Replaces: batch_distance / batch_distance_optimized (embedding/lorentz_model.py:141-210) and
  * _compute_pairwise_distances (hyperbolic_merge.py:166-190).  Engine-independent. */

@@ -249,3 +249,21 @@ def test_row_means_equal_numpy_mean_of_a_list():
             vals = [float(v) for v, k in zip(D[r].tolist(), keep[r].tolist()) if k]
             want = np.mean(vals) if vals else np.nan
             assert (np.isnan(want) and np.isnan(got[r])) or got[r] == want, (ns, r)
+
+
+def test_randperm_prefix_helper_equals_torch_randperm():
+    """hm_randperm_prefix (host helper of the library): same samples as torch.randperm(n)[:ns] and the same
+    generator state afterwards, across block boundaries of the MT19937 recurrence"""
+    from hyptokenizer_amd.tokenizer.enhanced_fast_hyperbolic_merge import randperm_prefixes
+    for seed, n, ns, count in [(0, 1, 1, 3), (1, 2, 2, 5), (2, 50, 50, 4), (3, 51, 50, 7), (4, 623, 50, 9), (5, 624, 50, 9),
+                               (6, 625, 50, 9), (7, 1249, 17, 6), (8, 100000, 50, 5), (9, 3001, 50, 300), (10, 40, 40, 40)]:
+        torch.manual_seed(seed)
+        torch.rand(seed % 7 + 1)                           # an arbitrary position inside a block
+        state = torch.get_rng_state()
+        want = np.stack([torch.randperm(n)[:ns].numpy() for _ in range(count)])
+        after = torch.get_rng_state()
+        torch.set_rng_state(state)
+        got = randperm_prefixes(n, ns, count)
+        assert np.array_equal(got, want), (seed, n, ns)
+        assert torch.equal(torch.get_rng_state(), after), (seed, n, ns)
+        assert torch.equal(torch.randperm(11), (torch.set_rng_state(after), torch.randperm(11))[1])

@@ -24,9 +24,9 @@ def prefilter_form(request, monkeypatch):
     survivors, the canonical arithmetic decides."""
     monkeypatch.setenv("HM_SCAN_PRECISION", request.param.split("-")[0])
     if request.param.endswith("-512"):
-        monkeypatch.setenv("HM_TUNE_TM4_ROWS", "2")
+        monkeypatch.setenv("HM_TUNE_BIG_ROWS", "2")
     else:
-        monkeypatch.delenv("HM_TUNE_TM4_ROWS", raising=False)
+        monkeypatch.delenv("HM_TUNE_BIG_ROWS", raising=False)
     return request.param
 
 
@@ -329,3 +329,197 @@ def test_threshold_inside_the_bulk_of_the_distances(oracle):
         a = eng.argmin(1.0, thr)
         assert (a[1], a[2]) == (int(oi[0]), int(oj[0])) and _bits([a[0]])[0] == _bits(od)[0]
     assert eng.scan_stats()["emitted"] < 100000                   # seeded + key read at block start: no first-tile flood
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2: batched merges, device-resident loops, uncounted top-k, the acceptance test of the emission cut,
+# golden candidate lists and edge fixtures straight on the HIP engine
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_merge_batch_equals_sequential_merges(oracle, mode):
+    """hm_merge_append_batch: a chain of merges (later ones read rows written by earlier ones) in one launch"""
+    n, d = 900, 33
+    X = lorentz_table(n, d, seed=6, scale=0.05)
+    engA, tabA = _engine(X, mode, n + 64)
+    engB, tabB = _engine(X, mode, n + 64)
+    I = np.array([3, 900, 901, 5, 902, 902], np.int32)
+    J = np.array([9, 4, 900, 903, 7, 902], np.int32)
+    W = np.array([0.5, 0.25, 2 / 3, 0.5, 0.1, 0.5], np.float32)
+    engA.merge_append_batch(I, J, W, 1.3, tabA, n)
+    for t in range(len(I)):
+        engB.merge_append(int(I[t]), int(J[t]), float(W[t]), 1.3, tabB, n + t)
+    assert engA.n == engB.n == n + len(I)
+    assert np.array_equal(_bits(tabA.cpu().numpy()), _bits(tabB.cpu().numpy()))
+    thr = 0.4
+    assert engA.argmin(1.3, thr) == engB.argmin(1.3, thr)
+    a, b = engA.topk(1.3, thr, 50), engB.topk(1.3, thr, 50)
+    assert a[3] == b[3] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(_bits(a[0]), _bits(b[0]))
+    engA.truncate(n + 2)
+    assert engA.n == n + 2
+
+
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+@pytest.mark.parametrize("n,d,thr", [(1200, 50, 0.42), (300, 10, 0.2), (2100, 100, 0.6)])
+def test_device_resident_loops_equal_the_oracle_loop(oracle, mode, n, d, thr):
+    """hm_std_merge_steps / hm_incr_merge_steps: K steps per call, records and rows bit-equal to the oracle's
+    step-by-step loop (lengths-driven weights, duplicates, NaN rows of the literal mode)"""
+    steps = 70
+    X = lorentz_table(n, d, seed=21, scale=0.05)
+    lens = [1 + (k % 3) for k in range(n)]
+    # oracle loop
+    Xo = np.zeros((n + 128, d + 1), np.float32)
+    Xo[:n] = X.numpy()
+    ol = list(lens)
+    want = []
+    cur = n
+    for _ in range(steps):
+        od, oi, oj, oc = oracle.pairwise_topk(Xo, cur, 1.0, float(np.float32(thr)), MODES[mode], 1)
+        if oc == 0:
+            break
+        i, j = int(oi[0]), int(oj[0])
+        w = np.float32(ol[j] / (ol[i] + ol[j]))
+        Xo[cur] = oracle.midpoint_batch(Xo, [i], [j], [w], 1.0, MODES[mode])[0]
+        ol.append(ol[i] + ol[j])
+        want.append((int(_bits(od[:1])[0]), i, j))
+        cur += 1
+    for kind in ("std", "incr"):
+        eng, table = _engine(X, mode, n + 128)
+        eng.set_token_lengths(lens)
+        got = []
+        best = eng.argmin(1.0, thr) if kind == "incr" else None
+        left = steps
+        while left > 0:
+            k = min(left, 64)
+            if kind == "std":
+                recs, done = eng.std_merge_steps(1.0, thr, table, k)
+            else:
+                recs, done, best = eng.incr_merge_steps(1.0, thr, table, k, best)
+            got += [(int(_bits([r[1]])[0]), r[2], r[3]) for r in recs[:done]]
+            left -= done
+            if done < k:
+                assert recs[done][0] in (0, 2)
+                if recs[done][0] == 2:                     # overflow (tie flood): this step through the host path
+                    a = eng.argmin(1.0, thr)
+                    li, lj = ol[a[1]], ol[a[2]]
+                    eng.merge_append(a[1], a[2], lj / (li + lj), 1.0, table, eng.n)
+                    eng.set_token_lengths(ol[:eng.n])
+                    got.append((int(_bits([a[0]])[0]), a[1], a[2]))
+                    left -= 1
+                    if kind == "incr":
+                        best = eng.argmin(1.0, thr)
+                else:
+                    break
+        assert got == want, kind
+        assert eng.n == cur
+        assert np.array_equal(_bits(table[:cur].cpu().numpy()), _bits(Xo[:cur])), kind
+        # the engine is in a consistent state afterwards: a plain search agrees with the oracle
+        od, oi, oj, oc = oracle.pairwise_topk(Xo, cur, 1.0, float(np.float32(thr)), MODES[mode], 5)
+        gd, gi, gj, gc = eng.topk(1.0, thr, 5)
+        assert gc == oc and np.array_equal(gi, oi) and np.array_equal(gj, oj)
+
+
+def test_uncounted_topk_and_late_count(oracle):
+    """topk(count=False) returns the same list; the exact total can be asked for later -- also after rows were
+    appended -- and equals the count of the table as it was (n_limit)"""
+    n, d = 4000, 60
+    X = lorentz_table(n, d, seed=9, scale=0.05)
+    eng, table = _engine(X, "lorentz", n + 64)
+    s = eng.pair_distance(np.arange(0, 1500), np.arange(1500, 3000), 1.0)
+    for q in (0.05, 2.0, 40.0):
+        thr = float(np.percentile(s, q))
+        full = eng.topk(1.0, thr, 500)
+        lazy = eng.topk(1.0, thr, 500, count=False)
+        assert np.array_equal(full[1], lazy[1]) and np.array_equal(full[2], lazy[2]) and np.array_equal(_bits(full[0]), _bits(lazy[0]))
+        assert lazy[3] in (-1, full[3]) and (lazy[3] == full[3] or full[3] >= 500)
+        assert eng.count_candidates(1.0, thr) == full[3]
+        eng.merge_append(int(full[1][0]), int(full[2][0]), 0.5, 1.0, table, eng.n)
+        assert eng.count_candidates(1.0, thr, n_limit=n) == full[3] or eng.n != n + 1
+        again = eng.topk(1.0, thr, 500, count=False)       # predicted cut of the previous refresh
+        oracle_d, oi, oj, oc = oracle.pairwise_topk(table.cpu().numpy(), eng.n, 1.0, float(np.float32(thr)), 1, 500)
+        assert np.array_equal(again[1], oi) and np.array_equal(again[2], oj) and np.array_equal(_bits(again[0]), _bits(oracle_d))
+        eng.truncate(n)
+
+
+def test_forced_tight_cut_is_detected(oracle):
+    """a cut that is too tight must not be accepted just because the undecided shell around a bulk
+    threshold holds >= k valid entries.  The next search is forced to start from a cut far below the k-th entry."""
+    n, d = 3000, 40
+    X = lorentz_table(n, d, seed=13, scale=0.05)
+    eng, table = _engine(X, "lorentz", n + 8)
+    s = eng.pair_distance(np.arange(0, 1000), np.arange(1000, 2000), 1.0)
+    thr = float(np.percentile(s, 35.0))                    # a threshold in the bulk: large undecided shell under bf16
+    k = 2000
+    od, oi, oj, oc = oracle.pairwise_topk(X.numpy(), n, 1.0, float(np.float32(thr)), 1, k)
+    u_small = np.float32(np.cosh(float(od[5])))            # cut at the 6th entry's u: far fewer than k below it
+    eng.debug_force_cut(int(u_small.view(np.uint32)), k, 1.0)
+    gd, gi, gj, gc = eng.topk(1.0, thr, k)
+    assert gc == oc and np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(_bits(gd), _bits(od))
+    eng.debug_force_cut(int(u_small.view(np.uint32)), k, 1.0)
+    gd, gi, gj, gc = eng.topk(1.0, thr, k, count=False)
+    assert np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(_bits(gd), _bits(od))
+
+
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_golden_candidate_lists_on_the_hip_engine(golden_dir, mode):
+    """G2 (reference's own _find_merge_candidates / _find_merge_candidates_fast lists) fed to the HIP engine
+    directly: identical (i, j) lists and counts, distances within 1e-5 (hyperbolic_merge.py:247-269,378,
+    fast...:91-95)"""
+    import os
+    z = np.load(os.path.join(golden_dir, f"g2_candidates_{mode}.npz"))
+    for (n, d) in [(64, 10), (101, 10), (257, 10), (1000, 10), (300, 50)]:
+        X = torch.from_numpy(z[f"n{n}_d{d}_X"])
+        thrs = z[f"n{n}_d{d}_thr"]
+        eng, _ = _engine(X, mode)
+        for ti, thr in enumerate(thrs.tolist()):
+            key = f"n{n}_d{d}_t{ti}"
+            if f"{key}_std_count" not in z.files:
+                continue
+            t32 = float(np.float32(thr))
+            if n <= 100:                                   # the reference's double-compare branch (:270-289)
+                t = np.float32(thr)
+                t32 = float(t if float(t) >= thr else np.nextafter(t, np.float32(np.inf)))
+            ci, cj, cd, total = eng.candidates(1.0, t32)
+            assert total == int(z[f"{key}_std_count"]), key
+            m = len(z[f"{key}_std_i"])
+            assert np.array_equal(ci[:m], z[f"{key}_std_i"]) and np.array_equal(cj[:m], z[f"{key}_std_j"]), key
+            assert np.allclose(cd[:m], z[f"{key}_std_d"], atol=1e-5), key
+            fd, fi, fj, fc = eng.topk(1.0, t32, 10000)
+            assert fc == int(z[f"{key}_fast_count"]), key
+            mf = min(len(fi), len(z[f"{key}_fast_i"]))
+            ref_d = z[f"{key}_fast_d"][:mf]
+            # the reference's order is by ITS fp32 distances; ours by the canonical ones: identical wherever the
+            # reference's neighbours differ by more than its own rounding noise -- compare as sets per distance tie group
+            assert np.allclose(fd[:mf], ref_d, atol=1e-5), key
+            same = (fi[:mf] == z[f"{key}_fast_i"][:mf]) & (fj[:mf] == z[f"{key}_fast_j"][:mf])
+            if not same.all():
+                bad = np.nonzero(~same)[0]
+                assert np.all(np.abs(ref_d[bad] - fd[bad]) <= 1e-6), key      # only swaps inside the noise
+                assert sorted(zip(fi[:mf].tolist(), fj[:mf].tolist())) == sorted(zip(z[f"{key}_fast_i"][:mf].tolist(), z[f"{key}_fast_j"][:mf].tolist())) or mf == 10000, key
+            assert min(int(fc), 10000) == int(z[f"{key}_cache_len"]), key
+
+
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_golden_edge_rows_on_the_hip_engine(oracle, golden_dir, mode):
+    """G1 edge fixture (identical rows, the origin, a NaN row, a zero row) as an engine table: pair distances,
+    candidate list and midpoints against the reference's values"""
+    import os
+    from helpers import nan_equal_close
+    z = np.load(os.path.join(golden_dir, f"g1_primitives_{mode}.npz"))
+    E = torch.from_numpy(z["edge_X"])
+    eng, table = _engine(E, mode, 64)
+    a, b = z["edge_pairs_a"], z["edge_pairs_b"]
+    got = eng.pair_distance(a, b, 1.0)
+    assert nan_equal_close(got, z["edge_dist"], 1e-5)
+    mid = eng.midpoint(a, b, np.full(len(a), 0.5, np.float32), 1.0).cpu().numpy()
+    assert nan_equal_close(mid, z["edge_mid"], 1e-5)
+    bd = z["edge_bd"]
+    n = E.shape[0]
+    ci, cj, cd, total = eng.candidates(1.0, 0.5)
+    want = [(i, j) for i in range(n) for j in range(i + 1, n) if bd[i, j] < np.float32(0.5)]      # NaN never passes
+    assert total == len(want) and list(zip(ci.tolist(), cj.tolist())) == want
+    best = eng.argmin(1.0, 0.5)
+    if want:
+        order = sorted(want, key=lambda p: (float(bd[p]), p))
+        assert best is not None and (best[1], best[2]) == order[0]
+    else:
+        assert best is None

@@ -1,0 +1,91 @@
+"""GPU: BASELINE config 5 (EnhancedFastHyperbolicTokenizer) through the HIP kernels -- hm_coherence_batch (fused
+midpoint + <= 50 gathered distances per candidate), hm_project_table (in-place re-projection + image refresh) --
+against the G5 goldens captured from the reference and, bit for bit, against the CPU oracle.
+The comparisons themselves live in tests/test_enhanced_golden.py (they run there on the oracle double)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import bits  # noqa: E402
+from test_enhanced_golden import (check_curvature, check_order, check_scores, check_sequences, load_g5)  # noqa: E402
+from hyptokenizer_amd.synthetic import lorentz_table  # noqa: E402
+
+MODES = {"reference": 0, "lorentz": 1}
+
+
+def hip_engine(rows, d1, mode):
+    from hyptokenizer_amd.engine import MergeEngine
+    return MergeEngine(rows, d1, mode, torch.device("cuda"))
+
+
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+def test_scores_order_and_sequences_match_reference(golden_dir, mode, tmp_path):
+    z, meta = load_g5(golden_dir, mode)
+    check_scores(z, meta, mode, hip_engine, device="cuda")
+    check_order(z, meta, mode, hip_engine, device="cuda")
+    check_sequences(z, meta, mode, hip_engine, device="cuda", tmp_path=tmp_path)
+
+
+def test_curvature_step_matches_patched_reference(golden_dir):
+    z, meta = load_g5(golden_dir, "lorentz")
+    check_curvature(z, meta, hip_engine, device="cuda")
+
+
+@pytest.mark.parametrize("mode", ["lorentz", "reference"])
+@pytest.mark.parametrize("n,d,ns", [(400, 10, 50), (3000, 100, 50), (700, 37, 17), (64, 5, 50), (130, 127, 3)])
+def test_coherence_kernel_equals_oracle(oracle, mode, n, d, ns):
+    """hm_coherence_batch vs oracle.coherence_distances, bit for bit (NaNs in the same places)"""
+    from hyptokenizer_amd.engine import MergeEngine
+    X = lorentz_table(n, d, seed=8, scale=0.05)
+    X[7] = X[3]                                            # identical rows: NaN tangent
+    eng = MergeEngine(n + 8, d + 1, mode)
+    table = torch.zeros((n + 8, d + 1), device="cuda")
+    table[:n] = X.cuda()
+    eng.set_table(table, n)
+    rs = np.random.RandomState(1)
+    b = 257
+    I = rs.randint(0, n, b).astype(np.int32)
+    J = rs.randint(0, n, b).astype(np.int32)
+    I[0], J[0] = 3, 7
+    W = rs.rand(b).astype(np.float32)
+    ns = min(ns, n)
+    S = np.stack([rs.permutation(n)[:ns] for _ in range(b)]).astype(np.int32)
+    got = eng.coherence_distances(I, J, W, S, 1.7)
+    Xo = np.zeros((n + 8, d + 1), np.float32)
+    Xo[:n] = X.numpy()
+    want = oracle.coherence_distances(Xo, I, J, W, S, 1.7, MODES[mode])
+    assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("d", [2, 10, 50, 100, 128])
+def test_project_table_equals_oracle_and_keeps_searches_exact(oracle, d):
+    """hm_project_table: table rows [0, max) bit-equal to the oracle's; the refreshed images give the same nearest
+    pair / top-k as an engine built from the projected table (both prefilter forms)"""
+    from hyptokenizer_amd.engine import MergeEngine
+    n, rows = 2500, 2600
+    X = lorentz_table(n, d, seed=2, scale=0.07)
+    Xo = np.zeros((rows, d + 1), np.float32)
+    Xo[:n] = X.numpy()
+    Xo[n - 1] = np.nan
+    for pre in ("bf16", "f32"):
+        table = torch.from_numpy(Xo.copy()).cuda()
+        eng = MergeEngine(rows, d + 1, "lorentz", prefilter=pre)
+        eng.set_table(table, n)
+        thr = 0.9 * float(np.median(eng.pair_distance(np.arange(0, 500), np.arange(500, 1000), 1.0)))
+        eng.argmin(1.0, thr)
+        eng.topk(1.0, thr, 300)
+        c = 2.3
+        eng.project_table(table, rows, c)
+        want = Xo.copy()
+        oracle.project_table(want, rows, c)
+        assert np.array_equal(bits(table.cpu().numpy()), bits(want))
+        thr2 = thr / np.sqrt(c)
+        od, oi, oj, oc = oracle.pairwise_topk(want, n, c, float(np.float32(thr2)), 1, 300)
+        a = eng.argmin(c, thr2)
+        assert (a is None) == (oc == 0)
+        if a is not None:
+            assert (a[1], a[2]) == (int(oi[0]), int(oj[0])) and bits([a[0]])[0] == bits(od)[0]
+        gd, gi, gj, gc = eng.topk(c, thr2, 300)
+        assert gc == oc and np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(bits(gd), bits(od))
