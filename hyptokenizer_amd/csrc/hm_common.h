@@ -38,7 +38,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ------------------------------------------------------------------------------------------------
 // constants
 // ------------------------------------------------------------------------------------------------
-#define HM_MAX_BLOCK_ROWS 512
+#define HM_MAX_BLOCK_ROWS 1024
 #define HM_MAX_D1 132              // largest table width (d + 1 <= 129) rounded up
 #define HM_TIE_SLACK 1024u         // ulps of u' that are treated as "may still order before" (d is 2.5-ulp monotone)
 #define HM_MODE_TOPK 0
@@ -128,6 +128,7 @@ struct hm_engine {
     // work-decomposition knobs (HM_TUNE_* environment overrides are a tuning aid)
     int chunk_f32 = 32, chunk_bf16 = 96, tail_div = 4;
     double tail_fraction = 0.20;
+    int force_shape = -1;                 // HM_TUNE_SHAPE: bf16 block shape of every launch (tuning builds)
     int64_t big_min_rows = 80000;         // bf16 form: launches covering at least the pairs of this many rows use 512-row blocks
     int64_t max_rows = 0, rows_alloc = 0, n = 0;
     int d1 = 0, d = 0, NG = 0, RS = 0, sign_mode = 0;

@@ -77,6 +77,7 @@ template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int SUB>
 __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
 {
     static_assert(SUB % 2 == 0, "the two accumulator sets alternate between column groups: an even number per tile");
+    constexpr bool PIPE = (TM <= 2);               // two accumulator sets fit the registers (128 stationary rows per wave: one set)
     constexpr int COLS = 32 * SUB;                 // partner rows per streamed tile
     constexpr int RS = hm_row_floats(NG);          // fp32 image: floats per row
     constexpr int RB16 = 32 * NG + 16;             // bf16 image: bytes per row (NG x 16 bf16 + [x0 fp32, pad])
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     __syncthreads();
 
     // ---- per-group pieces ----
-    f32x16 acc[2][TM];                              // two accumulator sets (see the header)
+    f32x16 acc[PIPE ? 2 : 1][TM];                   // two accumulator sets (see the header) where they fit
     uint4 bpre16 = make_uint4(0, 0, 0, 0);          // first B fragment of the NEXT group, requested by the previous one
     float2 bpre = make_float2(0.f, 0.f);
 
@@ -224,12 +225,12 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         constexpr int set = decltype(set_c)::value;
         constexpr bool RED = decltype(red_c)::value;
         constexpr int QN = 16 * TM;
-        if constexpr (RED) ext = acc[set ^ 1][0][0];
+        if constexpr (RED) ext = acc[PIPE ? (set ^ 1) : 0][0][0];
         auto fold = [&](int g) {
             if constexpr (RED) {
 #pragma unroll
                 for (int q = (g * QN) / NP; q < ((g + 1) * QN) / NP; ++q) {
-                    const float v = acc[set ^ 1][q / 16][q % 16];
+                    const float v = acc[PIPE ? (set ^ 1) : 0][q / 16][q % 16];
                     ext = SIGN ? __builtin_fmaxf(ext, v) : __builtin_fminf(ext, v);
                 }
             }
@@ -326,10 +327,16 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         bool wrote = false;
 #pragma unroll 1
         for (int st = 0; st < TM; ++st) {
-            f32x16 w = acc[set][0];
+            // element-wise select chain: a whole-vector `if (st == q) w = acc[q]` makes hipcc keep the accumulators
+            // in scratch memory in some instantiations (3x slower hot loop)
+            f32x16 w;
 #pragma unroll
-            for (int q = 1; q < TM; ++q)
-                if (st == q) w = acc[set][q];
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[set][0][e];
+#pragma unroll
+                for (int q = 1; q < TM; ++q) v = (st == q) ? acc[set][q][e] : v;
+                w[e] = v;
+            }
             if (TM > 1) {
                 float e1 = w[0];
 #pragma unroll
@@ -426,38 +433,56 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         }
         dma_tile(ct_next, buf_next);
 
-        // two groups per pass, the accumulator sets alternating (a rolled loop: two code sites for the slow path)
+        if constexpr (!PIPE) {
+            // one accumulator set: MFMAs, then the bound test of the same group (the other resident block of the CU
+            // fills the matrix pipe meanwhile); the first fragment of the next group is still requested early
+            bool prev = false;
 #pragma unroll 1
-        for (int sp = 0; sp < SUB / 2; ++sp) {
-            {
-                const int sub = 2 * sp;
+            for (int sub = 0; sub < SUB; ++sub) {
                 const int j0s = j0 + sub * 32;
                 const bool do_c = wave_active && (j0s + 31 > i0w);
-                float ext_u = 0.0f;
-                if (do_c && pend) {                           // the common case: one basic block, MFMAs + the other set's test
-                    mma_group(std::integral_constant<int, 0>{}, std::true_type{}, buf, sub, sp == 0, ext_u);
-                } else {
-                    if (do_c) mma_group(std::integral_constant<int, 0>{}, std::false_type{}, buf, sub, true, ext_u);
-                    if (pend) ext_u = reduce_group(std::integral_constant<int, 1>{});
+                if (do_c) {
+                    float ext_u = 0.0f;
+                    mma_group(std::integral_constant<int, 0>{}, std::false_type{}, buf, sub, !prev, ext_u);
+                    ext_u = reduce_group(std::integral_constant<int, 0>{});
+                    finish_group(std::integral_constant<int, 0>{}, ext_u, j0s);
                 }
-                if (pend) finish_group(std::integral_constant<int, 1>{}, ext_u, pend_j0s);
-                pend = do_c;
-                pend_j0s = j0s;
+                prev = do_c;
             }
-            {
-                const int sub = 2 * sp + 1;
-                const int j0s = j0 + sub * 32;
-                const bool do_c = wave_active && (j0s + 31 > i0w);
-                float ext_u = 0.0f;
-                if (do_c && pend) {                           // the previous group ran: its last k-step requested our first fragment
-                    mma_group(std::integral_constant<int, 1>{}, std::true_type{}, buf, sub, false, ext_u);
-                } else {
-                    if (do_c) mma_group(std::integral_constant<int, 1>{}, std::false_type{}, buf, sub, true, ext_u);
-                    if (pend) ext_u = reduce_group(std::integral_constant<int, 0>{});
+        } else {
+            // two groups per pass, the accumulator sets alternating (a rolled loop: two code sites for the slow path)
+#pragma unroll 1
+            for (int sp = 0; sp < SUB / 2; ++sp) {
+                {
+                    const int sub = 2 * sp;
+                    const int j0s = j0 + sub * 32;
+                    const bool do_c = wave_active && (j0s + 31 > i0w);
+                    float ext_u = 0.0f;
+                    if (do_c && pend) {                           // the common case: one basic block, MFMAs + the other set's test
+                        mma_group(std::integral_constant<int, 0>{}, std::true_type{}, buf, sub, sp == 0, ext_u);
+                    } else {
+                        if (do_c) mma_group(std::integral_constant<int, 0>{}, std::false_type{}, buf, sub, true, ext_u);
+                        if (pend) ext_u = reduce_group(std::integral_constant<int, 1>{});
+                    }
+                    if (pend) finish_group(std::integral_constant<int, 1>{}, ext_u, pend_j0s);
+                    pend = do_c;
+                    pend_j0s = j0s;
                 }
-                if (pend) finish_group(std::integral_constant<int, 0>{}, ext_u, pend_j0s);
-                pend = do_c;
-                pend_j0s = j0s;
+                {
+                    const int sub = 2 * sp + 1;
+                    const int j0s = j0 + sub * 32;
+                    const bool do_c = wave_active && (j0s + 31 > i0w);
+                    float ext_u = 0.0f;
+                    if (do_c && pend) {                           // the previous group ran: its last k-step requested our first fragment
+                        mma_group(std::integral_constant<int, 1>{}, std::true_type{}, buf, sub, false, ext_u);
+                    } else {
+                        if (do_c) mma_group(std::integral_constant<int, 1>{}, std::false_type{}, buf, sub, true, ext_u);
+                        if (pend) ext_u = reduce_group(std::integral_constant<int, 0>{});
+                    }
+                    if (pend) finish_group(std::integral_constant<int, 0>{}, ext_u, pend_j0s);
+                    pend = do_c;
+                    pend_j0s = j0s;
+                }
             }
         }
 
@@ -471,9 +496,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         __syncthreads();                                     // ... and every wave's; all reads of slot `buf` done
         if (++buf == NBUF) buf = 0;
     }
-    if (pend) {                                              // the last group of the run (set (SUB - 1) % 2 = 1)
-        const float ext_u = reduce_group(std::integral_constant<int, 1>{});
-        finish_group(std::integral_constant<int, 1>{}, ext_u, pend_j0s);
+    if constexpr (PIPE) {
+        if (pend) {                                          // the last group of the run (set (SUB - 1) % 2 = 1)
+            const float ext_u = reduce_group(std::integral_constant<int, 1>{});
+            finish_group(std::integral_constant<int, 1>{}, ext_u, pend_j0s);
+        }
     }
 
     if (MODE == HM_MODE_TOPK) {
@@ -538,31 +565,43 @@ bool hm_use_bf16(const hm_engine* e)
     return e->d >= 24;
 }
 
+// bf16 block shapes: 0 = 4 waves x 64 rows (256-row blocks, two accumulator sets), 1 = 4 waves x 128 rows (512-row
+// blocks: half the L2 -> LDS fill traffic and half the LDS fragment reads per flop, one accumulator set),
+// 2 = 8 x 64, 3 = 8 x 128 (tuning builds only)
+#ifndef HM_SCAN_ALL_SHAPES
+#define HM_SCAN_ALL_SHAPES 0
+#endif
+#define HM_BF16_CASES(TMv, WPBv)                                                                                           \
+    switch (e->KS) {                                                                                                       \
+        HM_BF16_SMALL(TMv, WPBv)                                                                                           \
+        case 7: return hm_launch_scan_ng<7, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);      \
+    }                                                                                                                      \
+    return hipErrorInvalidValue;
+#if HM_SCAN_INSTANTIATE_ALL
+#define HM_BF16_SMALL(TMv, WPBv)                                                                                           \
+        case 1: return hm_launch_scan_ng<1, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);      \
+        case 2: return hm_launch_scan_ng<2, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);      \
+        case 4: return hm_launch_scan_ng<4, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+#else
+#define HM_BF16_SMALL(TMv, WPBv)
+#endif
+
 hipError_t hm_launch_scan(hm_engine* e, int mode, const ScanArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
-    if (a.bf16 && a.shape == 1) {
-        switch (e->KS) {
-#if HM_SCAN_INSTANTIATE_ALL
-            case 1: return hm_launch_scan_ng<1, 1, 2, HM_WPB_BIG, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
-            case 2: return hm_launch_scan_ng<2, 1, 2, HM_WPB_BIG, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
-            case 4: return hm_launch_scan_ng<4, 1, 2, HM_WPB_BIG, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
-            case 8: return hm_launch_scan_ng<8, 1, 2, HM_WPB_BIG, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+    if (a.bf16 && a.shape == 1) { HM_BF16_CASES(4, 4) }
+#if HM_SCAN_ALL_SHAPES
+    if (a.bf16 && a.shape == 2) { HM_BF16_CASES(2, 8) }
+    if (a.bf16 && a.shape == 3) { HM_BF16_CASES(4, 8) }
 #endif
-            case 7: return hm_launch_scan_ng<7, 1, 2, HM_WPB_BIG, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
-        }
-        return hipErrorInvalidValue;
-    }
     if (a.bf16) {
-        switch (e->KS) {
+        if (e->KS == 8) {
 #if HM_SCAN_INSTANTIATE_ALL
-            case 1: return hm_launch_scan_ng<1, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
-            case 2: return hm_launch_scan_ng<2, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
-            case 4: return hm_launch_scan_ng<4, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
-            case 8: return hm_launch_scan_ng<8, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+            return hm_launch_scan_ng<8, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+#else
+            return hipErrorInvalidValue;
 #endif
-            case 7: return hm_launch_scan_ng<7, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
         }
-        return hipErrorInvalidValue;
+        HM_BF16_CASES(2, 4)
     }
     switch (e->NG) {
 #if HM_SCAN_INSTANTIATE_ALL
@@ -600,8 +639,11 @@ bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t r
     // large launches: 512-row blocks halve the L2 -> LDS fill traffic, which is what limits the bf16 form once the
     // launch tail no longer does (decided by the pairs this launch covers: a row-range search of a sharded run is
     // a small launch)
-    a.shape = (a.bf16 && hm_pairs_in_range(n, row_begin, row_end) >= e->big_min_rows * (e->big_min_rows - 1) / 2) ? 1 : 0;
-    const int block_rows = a.bf16 ? (a.shape ? 64 * HM_WPB_BIG : 256) : 256;
+    // (KS = 8 would not fit the registers of the 128-row waves)
+    a.shape = (a.bf16 && e->KS <= 7 && hm_pairs_in_range(n, row_begin, row_end) >= e->big_min_rows * (e->big_min_rows - 1) / 2) ? 1 : 0;
+    if (a.bf16 && e->KS <= 7 && e->force_shape >= 0) a.shape = e->force_shape;
+    static const int kShapeRows[4] = {256, 512, 512, 1024};
+    const int block_rows = a.bf16 ? kShapeRows[a.shape] : 256;
     const int cols = 32 * (a.bf16 ? HM_SUB_BF16 : HM_SUB_F32);     // partner rows per streamed tile
     a.n = (int)n;
     a.row_begin = (int)row_begin;

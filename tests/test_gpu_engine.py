@@ -343,7 +343,7 @@ def test_merge_batch_equals_sequential_merges(oracle, mode):
     engA, tabA = _engine(X, mode, n + 64)
     engB, tabB = _engine(X, mode, n + 64)
     I = np.array([3, 900, 901, 5, 902, 902], np.int32)
-    J = np.array([9, 4, 900, 903, 7, 902], np.int32)
+    J = np.array([9, 4, 900, 901, 7, 902], np.int32)
     W = np.array([0.5, 0.25, 2 / 3, 0.5, 0.1, 0.5], np.float32)
     engA.merge_append_batch(I, J, W, 1.3, tabA, n)
     for t in range(len(I)):
