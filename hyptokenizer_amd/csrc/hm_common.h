@@ -52,7 +52,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_TAIL_SOLO 2048u
 #define HM_ROWPASS_BLOCKS 256      // blocks of the one-row-vs-all reduction
 #define HM_PART_SLOTS 256          // partial records (>= HM_TAIL_BLOCKS, HM_ROWPASS_BLOCKS)
-#define HM_UNIT_SLOTS 1024         // per-row-block unit counters of the scan's work loop
 #define HM_LOOP_MAX_STEPS 64       // steps one device-resident loop call may enqueue
 
 // prefilter forms (hm_engine_create / hm_set_prefilter)
@@ -95,10 +94,6 @@ struct ScanArgs {
     int sample_stride;
     const uint32_t* rmax2_bits;   // [0] largest squared row norm, [1] largest squared spatial norm (float bits)
     const uint32_t* stop;         // device-resident loops: a non-zero word makes every block return at once (may be NULL)
-    // dynamic work distribution (TOPK / ARGMIN launches): a resident grid draws units of `unit_tiles` column tiles from
-    // per-row-block counters units[0 .. n_rb)
-    int dyn, unit_tiles, n_rb;
-    uint32_t* units;
 };
 
 // Seed of the argmin search's running key, kept on the device between searches: the key of the last
@@ -133,8 +128,6 @@ struct hm_engine {
     // work-decomposition knobs (HM_TUNE_* environment overrides are a tuning aid)
     int chunk_f32 = 32, chunk_bf16 = 96, tail_div = 4;
     double tail_fraction = 0.20;
-    int dyn_units = 16;                   // HM_TUNE_UNIT: tiles (64-column units) per draw of the scan's work loop; 0 = static grid
-    uint32_t* d_units = nullptr;          // per-row-block unit counters (HM_UNIT_SLOTS)
     int force_shape = -1;                 // HM_TUNE_SHAPE: bf16 block shape of every launch (tuning builds)
     int64_t big_min_rows = 80000;         // bf16 form: launches covering at least the pairs of this many rows use 512-row blocks
     int64_t max_rows = 0, rows_alloc = 0, n = 0;

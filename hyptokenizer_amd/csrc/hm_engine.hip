@@ -73,8 +73,6 @@ static int hm_engine_alloc(hm_engine* e)
     HM_HIP(hipMemset(e->d_loop, 0, sizeof(LoopState)));
     HM_HIP(hipMalloc(&e->d_len, sizeof(int32_t) * (size_t)e->max_rows));
     HM_HIP(hipMalloc(&e->d_parts, sizeof(ArgminPart) * HM_PART_SLOTS));
-    HM_HIP(hipMalloc(&e->d_units, sizeof(uint32_t) * HM_UNIT_SLOTS));
-    HM_HIP(hipMemset(e->d_units, 0, sizeof(uint32_t) * HM_UNIT_SLOTS));
     HM_HIP(hipMalloc(&e->d_hist, sizeof(uint32_t) * HM_DIGIT_BINS));
     HM_HIP(hipHostMalloc(&e->h, sizeof(HostCtl), hipHostMallocDefault));
     HM_HIP(hipHostMalloc(&e->h_sorted, sizeof(uint4) * (size_t)e->sorted_cap, hipHostMallocDefault));
@@ -124,7 +122,6 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     if (const char* t = getenv("HM_TUNE_TAIL")) { const double v = atof(t); if (v >= 0.0 && v <= 0.9) e->tail_fraction = v; }
     if (const char* t = getenv("HM_TUNE_BIG_ROWS")) { const long v = atol(t); if (v >= 0) e->big_min_rows = v; }
     else if (const char* t2 = getenv("HM_TUNE_TM4_ROWS")) { const long v = atol(t2); if (v >= 0) e->big_min_rows = v; }   // round-1 name
-    if (const char* t = getenv("HM_TUNE_UNIT")) { const int v = atoi(t); if (v >= 0 && v <= 4096) e->dyn_units = v; }
     if (const char* t = getenv("HM_TUNE_SHAPE")) { const int v = atoi(t); if (v >= 0 && v <= 3) e->force_shape = v; }
     if (const char* t = getenv("HM_TUNE_TAIL_DIV")) { const int v = atoi(t); if (v >= 1 && v <= 16) e->tail_div = v; }
     // emission buffers: every pair of the largest table when that is small, 2^24 entries (256 MiB) at most
@@ -150,7 +147,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
     void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts,
-                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_units};
+                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len};
     for (void* q : dev_ptrs)
         if (q) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);

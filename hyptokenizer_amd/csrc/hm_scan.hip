@@ -115,10 +115,25 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         for (int t = threadIdx.x; t < HM_HIST_BINS; t += NTHREADS) lhist[t] = 0;
     }
 
-    // (row block, run of column tiles) being processed; the stationary rows in registers belong to row block rb_cur
-    int rb = 0, ct0 = 0, ct1 = 0, rb_cur = -1;
-    int i0w = 0;                        // first stationary row of this wave
-    bool wave_active = false, rows_full = false;
+    // ---- which (row block, run of column tiles) this block owns ----
+    int rb, ct0, ct1;
+    if ((int)blockIdx.x < p.n_items_a) {
+        rb = p.rb_first + (int)blockIdx.x / p.chunks_a;
+        ct0 = p.ctmin_a + ((int)blockIdx.x % p.chunks_a) * p.ch_a;
+        ct1 = ct0 + p.ch_a;
+    } else {
+        const int it = (int)blockIdx.x - p.n_items_a;
+        rb = p.rb_split + it / p.chunks_b;
+        ct0 = p.ctmin_b + (it % p.chunks_b) * p.ch_b;
+        ct1 = ct0 + p.ch_b;
+    }
+    if (ct0 < (rb * BLOCK_ROWS) / COLS) ct0 = (rb * BLOCK_ROWS) / COLS;   // left of the diagonal: no i < j
+    if (ct1 > p.nct) ct1 = p.nct;
+    if (ct0 >= ct1) return;
+
+    const int i0w = rb * BLOCK_ROWS + wave * WAVE_ROWS;   // first stationary row of this wave
+    const bool wave_active = (i0w < p.row_end) && (i0w + WAVE_ROWS - 1 >= p.row_begin) && (i0w < p.n);
+    const bool rows_full = (i0w >= p.row_begin) && (i0w + WAVE_ROWS - 1 < p.row_end);
 
     // The MFMA result u_f (plain fmaf chain) and the canonical u_c (torch reduction order) are two
     // roundings of the same exact form; |u_f - u_c| <= delta (gamma_n bound on both, |terms| <= rmax2).
@@ -138,7 +153,6 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     // ---- stationary A fragments: lane (r, h) keeps its operands of every k-step in registers ----
     float2 a[BF ? 1 : TM][BF ? 1 : NP];            // fp32 form: 2 operands (two k-steps) per group
     uint4 a16[BF ? TM : 1][BF ? NP : 1];           // bf16 form: 8 bf16 per 16-wide k-step
-    auto load_a = [&]() {
     if constexpr (BF) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
@@ -163,7 +177,6 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             a[tm][NG].x = -a[tm][NG].x;            // time step: acc = S - x0*y0 = -M
         }
     }
-    };
 
     // ---- LDS-DMA of one tile: wave w moves the PPW consecutive pieces [w * PPW, (w + 1) * PPW), four per
     // statement, through inline asm so that hipcc neither sees nor drains them; pieces past NPIECE (slot padding)
@@ -174,6 +187,27 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * (uint32_t)TILE_LDS + (uint32_t)wave * (PPW * 1024u));
         hm_dma_run<PPW>(src, dst);
     };
+
+    // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
+    int ct_step = 1;
+    if (MODE == HM_MODE_HIST) {
+        ct_step = p.sample_stride;
+        ct0 += (ct_step - (ct0 + rb * 7) % ct_step) % ct_step;
+        if (ct0 >= ct1) return;
+    }
+    const int ntile = (ct1 - ct0 + ct_step - 1) / ct_step;
+    auto tile_at = [&](int t) { return ct0 + t * ct_step; };
+
+    // ring prologue: tiles 0 .. DIST-1 in flight (a repeat of the last tile when the run is shorter), tile 0 landed
+#pragma unroll
+    for (int q = 0; q < DIST; ++q) dma_tile(tile_at(q < ntile ? q : ntile - 1), q);
+    if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * PPW) : "memory");
+    // hipcc waits for its own loads (the A fragments above) lazily, at their first use INSIDE the loop -- with
+    // vmcnt(N) instructions that also wait for the ring's LDS-DMA (which it cannot see) on every iteration.
+    // A wait it can see, here, settles them before the loop is entered.
+    if (DIST == 1) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+    __syncthreads();
 
     // ---- per-group pieces ----
     f32x16 acc[PIPE ? 2 : 1][TM];                   // two accumulator sets (see the header) where they fit
@@ -379,96 +413,6 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         }
     };
 
-    // ---- work distribution ----
-    // HIST launches (sampled estimate passes): static, block b owns item b of the host's list.  TOPK / ARGMIN launches:
-    // a resident grid takes UNITS of p.unit_tiles column tiles from per-row-block counters -- a block keeps drawing
-    // from the row block whose rows it holds in registers, and moves on (reloading them) only when that one is used
-    // up -- so the launch has no tail of unequal blocks and no block start-up per unit of work.
-    uint32_t* ctl = reinterpret_cast<uint32_t*>(smem + NBUF * TILE_LDS + 32 * ROW_BYTES + (MODE == HM_MODE_HIST ? 4 * HM_HIST_BINS : 0));
-    int probe_from = 0;
-    if (p.dyn) {
-        // start on the row block at this block's share of the triangle's work (row block q owns ~ (1 - q / n_rb) of it)
-        const float f = ((float)blockIdx.x + 0.5f) / (float)gridDim.x;
-        probe_from = (int)((float)p.n_rb * (1.0f - __builtin_sqrtf(1.0f - f)));
-        if (probe_from >= p.n_rb) probe_from = p.n_rb - 1;
-    }
-    for (;;) {
-    if (p.dyn) {
-        if (wave == 0) {
-            int got_rb = -1;
-            uint32_t got_unit = 0;
-            for (int base = 0; base < p.n_rb && got_rb < 0; base += 64) {
-                const int q = base + lane;
-                int rbi = probe_from + q;
-                if (rbi >= p.n_rb) rbi -= p.n_rb;
-                const int ctmin = ((p.rb_first + rbi) * BLOCK_ROWS) / COLS;
-                const uint32_t total = q < p.n_rb && p.nct > ctmin ? (uint32_t)((p.nct - ctmin + p.unit_tiles - 1) / p.unit_tiles) : 0u;
-                const uint32_t seen = q < p.n_rb ? __hip_atomic_load(&p.units[rbi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-                unsigned long long mask = __ballot(seen < total);
-                while (mask != 0ull && got_rb < 0) {
-                    const int l = __builtin_ctzll(mask);
-                    mask &= mask - 1ull;
-                    uint32_t u = 0;
-                    if (lane == l) u = atomicAdd(&p.units[rbi], 1u);
-                    u = __shfl(u, l, 64);
-                    const uint32_t tot_l = __shfl(total, l, 64);
-                    if (u < tot_l) { got_rb = __shfl(rbi, l, 64); got_unit = u; }
-                }
-            }
-            if (lane == 0) { ctl[0] = (uint32_t)got_rb; ctl[1] = got_unit; }
-        }
-        __syncthreads();
-        const int got_rb = (int)ctl[0];
-        const uint32_t got_unit = ctl[1];
-        __syncthreads();
-        if (got_rb < 0) break;                                // every row block is used up
-        probe_from = got_rb;                                  // stay with this row block while it has units
-        rb = p.rb_first + got_rb;
-        ct0 = (rb * BLOCK_ROWS) / COLS + (int)got_unit * p.unit_tiles;
-        ct1 = ct0 + p.unit_tiles;
-    } else if ((int)blockIdx.x < p.n_items_a) {
-        rb = p.rb_first + (int)blockIdx.x / p.chunks_a;
-        ct0 = p.ctmin_a + ((int)blockIdx.x % p.chunks_a) * p.ch_a;
-        ct1 = ct0 + p.ch_a;
-    } else {
-        const int it = (int)blockIdx.x - p.n_items_a;
-        rb = p.rb_split + it / p.chunks_b;
-        ct0 = p.ctmin_b + (it % p.chunks_b) * p.ch_b;
-        ct1 = ct0 + p.ch_b;
-    }
-    if (ct0 < (rb * BLOCK_ROWS) / COLS) ct0 = (rb * BLOCK_ROWS) / COLS;   // left of the diagonal: no i < j
-    if (ct1 > p.nct) ct1 = p.nct;
-    if (ct0 >= ct1) { if (p.dyn) continue; else break; }
-
-    if (rb != rb_cur) {
-        rb_cur = rb;
-        i0w = rb * BLOCK_ROWS + wave * WAVE_ROWS;
-        wave_active = (i0w < p.row_end) && (i0w + WAVE_ROWS - 1 >= p.row_begin) && (i0w < p.n);
-        rows_full = (i0w >= p.row_begin) && (i0w + WAVE_ROWS - 1 < p.row_end);
-        load_a();
-    }
-
-    // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
-    int ct_step = 1;
-    if (MODE == HM_MODE_HIST) {
-        ct_step = p.sample_stride;
-        ct0 += (ct_step - (ct0 + rb * 7) % ct_step) % ct_step;
-        if (ct0 >= ct1) break;
-    }
-    const int ntile = (ct1 - ct0 + ct_step - 1) / ct_step;
-    auto tile_at = [&](int t) { return ct0 + t * ct_step; };
-
-    // ring prologue: tiles 0 .. DIST-1 in flight (a repeat of the last tile when the run is shorter), tile 0 landed
-#pragma unroll
-    for (int q = 0; q < DIST; ++q) dma_tile(tile_at(q < ntile ? q : ntile - 1), q);
-    if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * PPW) : "memory");
-    // hipcc waits for its own loads (the A fragments above) lazily, at their first use INSIDE the loop -- with
-    // vmcnt(N) instructions that also wait for the ring's LDS-DMA (which it cannot see) on every iteration.
-    // A wait it can see, here, settles them before the loop is entered.
-    if (DIST == 1) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
-    __syncthreads();
-
     bool pend = false;               // a finished group waits in the other accumulator set for its bound test
     int pend_j0s = 0;
     int buf = 0;                     // ring slot of tile t
@@ -559,10 +503,6 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         }
     }
 
-    if (DIST > 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // nothing of this run may land later
-    if (!p.dyn) break;
-    }   // work loop
-
     if (MODE == HM_MODE_TOPK) {
         // one 64-bit atomic per wave for the sure count
         unsigned long long s = sure_total;
@@ -588,7 +528,6 @@ static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, h
     size_t lds = ((BF ? HM_DIST_BF16 : 1) + 1) * ppw * WPB * 1024;
     lds += (size_t)32 * (BF ? (32 * NG + 16) : 4 * hm_row_floats(NG));     // slack behind the ring: the early request of "the next group's" fragment
     if (MODE == HM_MODE_HIST) lds += sizeof(uint32_t) * HM_HIST_BINS;      // (HIST mode keeps its bins there; they are only read by that request)
-    lds += 64;                                                              // the work loop's two control words
     const void* fn = reinterpret_cast<const void*>(&hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>);
     if (lds > 48 * 1024 && e->attr_done.find(fn) == e->attr_done.end()) {     // per engine (= per device), not process-wide
         hipError_t st = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -597,24 +536,8 @@ static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, h
     }
     // timed launches carry their events in the dispatch itself (start / stop timestamps of this kernel): a pair of
     // hipEventRecord calls around it costs two ~6 us bubbles on the stream
-    ScanArgs b = a;
-    if (MODE != HM_MODE_HIST && e->dyn_units > 0) {
-        // resident grid + per-row-block unit counters (see the kernel's work loop)
-        constexpr int block_rows = 32 * TM * WPB, cols = 32 * SUB;
-        b.dyn = 1;
-        b.unit_tiles = std::max(1, e->dyn_units * 64 / cols);              // (the knob is in 64-column units)
-        b.n_rb = (a.row_end - 1) / block_rows - a.rb_first + 1;
-        b.units = e->d_units;
-        long long units_total = 0;
-        for (int q = 0; q < b.n_rb; ++q) {
-            const int ctmin = ((a.rb_first + q) * block_rows) / cols;
-            if (a.nct > ctmin) units_total += (a.nct - ctmin + b.unit_tiles - 1) / b.unit_tiles;
-        }
-        const long long resident = (long long)e->n_cu * (WPB >= 8 ? 1 : 2);
-        grid = dim3((unsigned)std::max<long long>(1, std::min(resident, units_total)), 1, 1);
-    }
-    if (ev0 != nullptr) hipExtLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, ev0, ev1, 0, b);
-    else hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, b);
+    if (ev0 != nullptr) hipExtLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, a);
     return hipGetLastError();
 }
 

@@ -27,7 +27,6 @@ struct TailArgs {
     ArgminSeed* seed;                // may be NULL: no seed update
     int bf, kterms;
     uint32_t* rmax2_bits;
-    uint32_t* units;                 // unit counters of the scan's work loop (re-armed)
     int arm, arm_rb, arm_re;         // leave counters + running key ready for the next search of rows [arm_rb, arm_re)
     MergeFuse mf;
 };
@@ -127,14 +126,11 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
     }
     // arm the next search over the same row range: emitted = 0, running key = seed -- the merge loop then goes from
     // this kernel straight into the next scan
-    if (a.arm && found != 2u) {
-        for (int q = lane; q < HM_UNIT_SLOTS; q += 64) a.units[q] = 0u;
-        if (lane == 0) {
-            const bool use = seed_row != 0xffffffffu && (int)seed_row >= a.arm_rb && (int)seed_row < a.arm_re;
-            a.ctr64[0] = 0ull;
-            a.ctr64[1] = use ? seed_key : ~0ull;
-            a.ctr64[2] = 0ull;
-        }
+    if (a.arm && found != 2u && lane == 0) {
+        const bool use = seed_row != 0xffffffffu && (int)seed_row >= a.arm_rb && (int)seed_row < a.arm_re;
+        a.ctr64[0] = 0ull;
+        a.ctr64[1] = use ? seed_key : ~0ull;
+        a.ctr64[2] = 0ull;
     }
     // ---- fused merge of the pair just found (device-resident loop) ----
     if (a.mf.X != nullptr) {
@@ -165,7 +161,7 @@ int hm_launch_argmin_tail(hm_engine* e, const ScanArgs& sa, float sqrt_c, float 
     t.parts = e->d_parts; t.ticket = e->d_ctr + 6;
     t.out = rec_out; t.out2 = (rec_out == e->d_rec) ? e->d_rec + 1 : nullptr;
     t.seed = with_seed ? e->d_seed : nullptr;
-    t.bf = sa.bf16; t.kterms = sa.bf16 ? 16 * e->KS : e->RS; t.rmax2_bits = e->d_rmax2; t.units = e->d_units;
+    t.bf = sa.bf16; t.kterms = sa.bf16 ? 16 * e->KS : e->RS; t.rmax2_bits = e->d_rmax2;
     t.arm = arm ? 1 : 0; t.arm_rb = arm_rb; t.arm_re = arm_re;
     t.mf = mf;
     hipLaunchKernelGGL(hm_argmin_tail_kernel, dim3(HM_TAIL_BLOCKS), dim3(HM_TAIL_THREADS), 0, s, t);
@@ -175,10 +171,9 @@ int hm_launch_argmin_tail(hm_engine* e, const ScanArgs& sa, float sqrt_c, float 
 
 // counters + running-key seed of an argmin search that was not armed by its predecessor
 __global__ void hm_seed_init_kernel(const ArgminSeed* __restrict__ seed, unsigned long long* __restrict__ ctr64, uint32_t* __restrict__ ctr,
-                                    uint32_t* __restrict__ units, int row_begin, int row_end)
+                                    int row_begin, int row_end)
 {
     if (threadIdx.x < 8) ctr[threadIdx.x] = 0u;
-    for (int q = threadIdx.x; q < HM_UNIT_SLOTS; q += blockDim.x) units[q] = 0u;
     if (threadIdx.x == 0) {
         const bool use = seed->valid != 0u && (int)seed->i >= row_begin && (int)seed->i < row_end;
         ctr64[0] = 0ull;
@@ -190,7 +185,7 @@ __global__ void hm_seed_init_kernel(const ArgminSeed* __restrict__ seed, unsigne
 
 int hm_launch_seed_init(hm_engine* e, const ScanArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, e->d_ctr64, e->d_ctr, e->d_units, a.row_begin, a.row_end);
+    hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, e->d_ctr64, e->d_ctr, a.row_begin, a.row_end);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
@@ -613,7 +608,6 @@ static int hm_topk_core_form(hm_engine* e, float c, float thr, int64_t k, int64_
         a.tie_imax = tie_imax;
         HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
         HM_HIP(hipMemsetAsync(e->d_ctr64, 0, sizeof(unsigned long long) * 4, s));
-        HM_HIP(hipMemsetAsync(e->d_units, 0, sizeof(uint32_t) * HM_UNIT_SLOTS, s));
         HM_HIP(hm_launch_scan(e, HM_MODE_TOPK, a, grid, s, e->ev0, e->ev1));
         hipLaunchKernelGGL(hm_post_distance_kernel, dim3(1024), dim3(256), 0, s, e->ent, e->d_ctr64, e->ent_cap, e->img, e->RS, e->d,
                            e->sign_mode, sqrt_c, thr, cut_bits, tie_imax, e->d_ctr + 1);
@@ -738,7 +732,6 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
             }
         } else {
             HM_HIP(hipMemsetAsync(e->d_ctr64 + 2, 0, sizeof(unsigned long long), s));     // emitted = 0, running key kept
-            HM_HIP(hipMemsetAsync(e->d_units, 0, sizeof(uint32_t) * HM_UNIT_SLOTS, s));
         }
         HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, e->ev0, e->ev1));
         int rc = hm_launch_argmin_tail(e, a, sqrt_c, thr, e->d_rec, true, (int)req_rb, arm_re, true, kNoMerge, s);
