@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
 #include <set>
 #include <string>
 #include <vector>
@@ -94,6 +95,10 @@ struct ScanArgs {
     int sample_stride;
     const uint32_t* rmax2_bits;   // [0] largest squared row norm, [1] largest squared spatial norm (float bits)
     const uint32_t* stop;         // device-resident loops: a non-zero word makes every block return at once (may be NULL)
+    // persistent work distribution (TOPK / ARGMIN launches): the launch's tiles form one row-major sequence of p_total
+    // tiles over n_rb row blocks; a resident grid walks equal shares of it
+    int persist, n_rb;
+    long long p_total;
 };
 
 // Seed of the argmin search's running key, kept on the device between searches: the key of the last
@@ -128,6 +133,8 @@ struct hm_engine {
     // work-decomposition knobs (HM_TUNE_* environment overrides are a tuning aid)
     int chunk_f32 = 32, chunk_bf16 = 96, tail_div = 4;
     double tail_fraction = 0.20;
+    int persist = 0;                      // HM_TUNE_PERSIST=1: resident grid walking equal shares of the tile sequence (experiment: slower)
+    std::map<const void*, int> occupancy;  // resident blocks per CU of each scan kernel
     int force_shape = -1;                 // HM_TUNE_SHAPE: bf16 block shape of every launch (tuning builds)
     int64_t big_min_rows = 80000;         // bf16 form: launches covering at least the pairs of this many rows use 512-row blocks
     int64_t max_rows = 0, rows_alloc = 0, n = 0;

@@ -115,25 +115,10 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         for (int t = threadIdx.x; t < HM_HIST_BINS; t += NTHREADS) lhist[t] = 0;
     }
 
-    // ---- which (row block, run of column tiles) this block owns ----
-    int rb, ct0, ct1;
-    if ((int)blockIdx.x < p.n_items_a) {
-        rb = p.rb_first + (int)blockIdx.x / p.chunks_a;
-        ct0 = p.ctmin_a + ((int)blockIdx.x % p.chunks_a) * p.ch_a;
-        ct1 = ct0 + p.ch_a;
-    } else {
-        const int it = (int)blockIdx.x - p.n_items_a;
-        rb = p.rb_split + it / p.chunks_b;
-        ct0 = p.ctmin_b + (it % p.chunks_b) * p.ch_b;
-        ct1 = ct0 + p.ch_b;
-    }
-    if (ct0 < (rb * BLOCK_ROWS) / COLS) ct0 = (rb * BLOCK_ROWS) / COLS;   // left of the diagonal: no i < j
-    if (ct1 > p.nct) ct1 = p.nct;
-    if (ct0 >= ct1) return;
-
-    const int i0w = rb * BLOCK_ROWS + wave * WAVE_ROWS;   // first stationary row of this wave
-    const bool wave_active = (i0w < p.row_end) && (i0w + WAVE_ROWS - 1 >= p.row_begin) && (i0w < p.n);
-    const bool rows_full = (i0w >= p.row_begin) && (i0w + WAVE_ROWS - 1 < p.row_end);
+    // (row block, run of column tiles) being processed; the stationary rows in registers belong to row block rb_cur
+    int rb = 0, ct0 = 0, ct1 = 0, rb_cur = -1;
+    int i0w = 0;                        // first stationary row of this wave
+    bool wave_active = false, rows_full = false;
 
     // The MFMA result u_f (plain fmaf chain) and the canonical u_c (torch reduction order) are two
     // roundings of the same exact form; |u_f - u_c| <= delta (gamma_n bound on both, |terms| <= rmax2).
@@ -153,6 +138,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     // ---- stationary A fragments: lane (r, h) keeps its operands of every k-step in registers ----
     float2 a[BF ? 1 : TM][BF ? 1 : NP];            // fp32 form: 2 operands (two k-steps) per group
     uint4 a16[BF ? TM : 1][BF ? NP : 1];           // bf16 form: 8 bf16 per 16-wide k-step
+    auto load_a = [&]() {
     if constexpr (BF) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
@@ -177,6 +163,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             a[tm][NG].x = -a[tm][NG].x;            // time step: acc = S - x0*y0 = -M
         }
     }
+    };
 
     // ---- LDS-DMA of one tile: wave w moves the PPW consecutive pieces [w * PPW, (w + 1) * PPW), four per
     // statement, through inline asm so that hipcc neither sees nor drains them; pieces past NPIECE (slot padding)
@@ -187,27 +174,6 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * (uint32_t)TILE_LDS + (uint32_t)wave * (PPW * 1024u));
         hm_dma_run<PPW>(src, dst);
     };
-
-    // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
-    int ct_step = 1;
-    if (MODE == HM_MODE_HIST) {
-        ct_step = p.sample_stride;
-        ct0 += (ct_step - (ct0 + rb * 7) % ct_step) % ct_step;
-        if (ct0 >= ct1) return;
-    }
-    const int ntile = (ct1 - ct0 + ct_step - 1) / ct_step;
-    auto tile_at = [&](int t) { return ct0 + t * ct_step; };
-
-    // ring prologue: tiles 0 .. DIST-1 in flight (a repeat of the last tile when the run is shorter), tile 0 landed
-#pragma unroll
-    for (int q = 0; q < DIST; ++q) dma_tile(tile_at(q < ntile ? q : ntile - 1), q);
-    if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * PPW) : "memory");
-    // hipcc waits for its own loads (the A fragments above) lazily, at their first use INSIDE the loop -- with
-    // vmcnt(N) instructions that also wait for the ring's LDS-DMA (which it cannot see) on every iteration.
-    // A wait it can see, here, settles them before the loop is entered.
-    if (DIST == 1) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
-    __syncthreads();
 
     // ---- per-group pieces ----
     f32x16 acc[PIPE ? 2 : 1][TM];                   // two accumulator sets (see the header) where they fit
@@ -413,6 +379,78 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         }
     };
 
+    // ---- work distribution ----
+    // HIST launches (sampled estimate passes): static, block b owns item b of the host's list.
+    // TOPK / ARGMIN launches (p.persist): the tiles right of the diagonal of the launch's row blocks, in row-major order,
+    // form ONE sequence of p.p_total tiles; the grid is exactly the blocks that are resident at once, and block b walks
+    // the share [b, b + 1) * p_total / gridDim.x of it -- equal work per block, no launch tail, one block start per
+    // slot -- reloading its stationary rows when the share crosses into the next row block (once or twice per block).
+    constexpr int TPR = BLOCK_ROWS / COLS;                     // diagonal advance per row block, in tiles
+    static_assert(BLOCK_ROWS % COLS == 0, "row blocks start on a tile boundary");
+    // tiles of the sequence in front of relative row block q
+    auto seq_before = [&](long long q) { return q * p.nct - (long long)TPR * ((long long)p.rb_first * q + q * (q - 1) / 2); };
+    long long pos = 0, pos_end = 0;
+    if (p.persist) {
+        pos = p.p_total * (long long)blockIdx.x / (long long)gridDim.x;
+        pos_end = p.p_total * ((long long)blockIdx.x + 1) / (long long)gridDim.x;
+    }
+    for (;;) {
+    if (p.persist) {
+        if (pos >= pos_end) break;
+        int lo = 0, hi = p.n_rb - 1;                           // largest q with seq_before(q) <= pos
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seq_before(mid) <= pos) lo = mid; else hi = mid - 1;
+        }
+        const long long q0 = seq_before(lo), q1 = seq_before(lo + 1);
+        const long long run_end = pos_end < q1 ? pos_end : q1;
+        rb = p.rb_first + lo;
+        ct0 = rb * TPR + (int)(pos - q0);
+        ct1 = ct0 + (int)(run_end - pos);
+        pos = run_end;
+    } else if ((int)blockIdx.x < p.n_items_a) {
+        rb = p.rb_first + (int)blockIdx.x / p.chunks_a;
+        ct0 = p.ctmin_a + ((int)blockIdx.x % p.chunks_a) * p.ch_a;
+        ct1 = ct0 + p.ch_a;
+    } else {
+        const int it = (int)blockIdx.x - p.n_items_a;
+        rb = p.rb_split + it / p.chunks_b;
+        ct0 = p.ctmin_b + (it % p.chunks_b) * p.ch_b;
+        ct1 = ct0 + p.ch_b;
+    }
+    if (ct0 < (rb * BLOCK_ROWS) / COLS) ct0 = (rb * BLOCK_ROWS) / COLS;   // left of the diagonal: no i < j
+    if (ct1 > p.nct) ct1 = p.nct;
+    if (ct0 >= ct1) { if (p.persist) continue; else break; }
+
+    if (rb != rb_cur) {
+        rb_cur = rb;
+        i0w = rb * BLOCK_ROWS + wave * WAVE_ROWS;
+        wave_active = (i0w < p.row_end) && (i0w + WAVE_ROWS - 1 >= p.row_begin) && (i0w < p.n);
+        rows_full = (i0w >= p.row_begin) && (i0w + WAVE_ROWS - 1 < p.row_end);
+        load_a();
+    }
+
+    // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
+    int ct_step = 1;
+    if (MODE == HM_MODE_HIST) {
+        ct_step = p.sample_stride;
+        ct0 += (ct_step - (ct0 + rb * 7) % ct_step) % ct_step;
+        if (ct0 >= ct1) break;
+    }
+    const int ntile = (ct1 - ct0 + ct_step - 1) / ct_step;
+    auto tile_at = [&](int t) { return ct0 + t * ct_step; };
+
+    // ring prologue: tiles 0 .. DIST-1 in flight (a repeat of the last tile when the run is shorter), tile 0 landed
+#pragma unroll
+    for (int q = 0; q < DIST; ++q) dma_tile(tile_at(q < ntile ? q : ntile - 1), q);
+    if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DIST - 1) * PPW) : "memory");
+    // hipcc waits for its own loads (the A fragments above) lazily, at their first use INSIDE the loop -- with
+    // vmcnt(N) instructions that also wait for the ring's LDS-DMA (which it cannot see) on every iteration.
+    // A wait it can see, here, settles them before the loop is entered.
+    if (DIST == 1) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+    __syncthreads();
+
     bool pend = false;               // a finished group waits in the other accumulator set for its bound test
     int pend_j0s = 0;
     int buf = 0;                     // ring slot of tile t
@@ -503,6 +541,10 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         }
     }
 
+    if (DIST > 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // nothing of this run may land later
+    if (!p.persist) break;
+    }   // work loop
+
     if (MODE == HM_MODE_TOPK) {
         // one 64-bit atomic per wave for the sure count
         unsigned long long s = sure_total;
@@ -536,8 +578,25 @@ static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, h
     }
     // timed launches carry their events in the dispatch itself (start / stop timestamps of this kernel): a pair of
     // hipEventRecord calls around it costs two ~6 us bubbles on the stream
-    if (ev0 != nullptr) hipExtLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, ev0, ev1, 0, a);
-    else hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, a);
+    ScanArgs b = a;
+    if (MODE != HM_MODE_HIST && e->persist) {
+        // resident grid, equal shares of the tile sequence (see the kernel's work loop)
+        constexpr int block_rows = 32 * TM * WPB, cols = 32 * SUB, tpr = block_rows / cols;
+        const long long nrb = (a.row_end - 1) / block_rows - a.rb_first + 1;
+        b.persist = 1;
+        b.n_rb = (int)nrb;
+        b.p_total = nrb * a.nct - (long long)tpr * ((long long)a.rb_first * nrb + nrb * (nrb - 1) / 2);
+        auto it = e->occupancy.find(fn);
+        int per_cu = 0;
+        if (it == e->occupancy.end()) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WPB, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            e->occupancy[fn] = per_cu;
+        } else per_cu = it->second;
+        const long long resident = (long long)e->n_cu * per_cu;
+        grid = dim3((unsigned)std::max<long long>(1, std::min(resident, b.p_total / 4)), 1, 1);
+    }
+    if (ev0 != nullptr) hipExtLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, ev0, ev1, 0, b);
+    else hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, b);
     return hipGetLastError();
 }
 

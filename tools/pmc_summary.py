@@ -35,6 +35,10 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c:
     der["mfma_busy_fraction_of_simd_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c.get("GRBM_GUI_ACTIVE", 0) * 128) if c.get("GRBM_GUI_ACTIVE") else None
 if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
     der["wave_cycles_waiting_fraction"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+if "SQ_WAIT_INST_LDS" in c and "SQ_WAVE_CYCLES" in c:
+    der["wave_cycles_waiting_on_lds_fraction"] = c["SQ_WAIT_INST_LDS"] / c["SQ_WAVE_CYCLES"]
+if "SQ_BUSY_CU_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
+    der["cu_busy_fraction"] = c["SQ_BUSY_CU_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 32)
 if "SQ_LDS_BANK_CONFLICT" in c and "SQ_LDS_IDX_ACTIVE" in c:
     der["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
 json.dump({"kernel_filter": kern, "counters": c, "derived": der}, open(out, "w"), indent=1)
