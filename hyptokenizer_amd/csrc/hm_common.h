@@ -317,6 +317,22 @@ __device__ __forceinline__ float hm_img_u_halfwave(const float* img, int RS, int
     return sign_mode ? m : -m;
 }
 
+// A half-wave works through 32 items: item k's canonical u is computed by the 32 lanes together (u_of(k) returns it on
+// every lane; both half-waves of the wave call in step, each for its own item k) and parked in lane k.  The caller then
+// finishes ITS item once -- acosh, threshold, key -- in parallel over the lanes instead of 32 times redundantly.
+template <class UF>
+__device__ __forceinline__ float hm_halfwave_gather32(int lane, UF u_of)
+{
+    const int t = lane & 31;
+    float mine = 0.0f;
+#pragma unroll 4
+    for (int k = 0; k < 32; ++k) {
+        const float u = u_of(k);
+        mine = (t == k) ? u : mine;
+    }
+    return mine;
+}
+
 __device__ __forceinline__ bool hm_key_less(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2)
 {
     if (a0 != b0) return a0 < b0;

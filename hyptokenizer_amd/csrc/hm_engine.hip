@@ -122,7 +122,7 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     if (const char* t = getenv("HM_TUNE_TAIL")) { const double v = atof(t); if (v >= 0.0 && v <= 0.9) e->tail_fraction = v; }
     if (const char* t = getenv("HM_TUNE_BIG_ROWS")) { const long v = atol(t); if (v >= 0) e->big_min_rows = v; }
     else if (const char* t2 = getenv("HM_TUNE_TM4_ROWS")) { const long v = atol(t2); if (v >= 0) e->big_min_rows = v; }   // round-1 name
-    if (const char* t = getenv("HM_TUNE_PERSIST")) e->persist = atoi(t) != 0 ? 1 : 0;
+    if (const char* t = getenv("HM_TUNE_PERSIST")) { const int v = atoi(t); if (v >= 0 && v <= 9) e->persist = v; }
     if (const char* t = getenv("HM_TUNE_SHAPE")) { const int v = atoi(t); if (v >= 0 && v <= 3) e->force_shape = v; }
     if (const char* t = getenv("HM_TUNE_TAIL_DIV")) { const int v = atoi(t); if (v >= 1 && v <= 16) e->tail_div = v; }
     // emission buffers: every pair of the largest table when that is small, 2^24 entries (256 MiB) at most

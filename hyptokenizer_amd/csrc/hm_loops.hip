@@ -177,20 +177,23 @@ __global__ __launch_bounds__(512) void hm_incr_step_kernel(const IncrArgs a)
     // ---- nearest partner of the new row among rows [0, new_row): a half-wave per partner row ----
     uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
     {
-        const int d = a.d, RS = a.RS;
+        const int d = a.d, RS = a.RS, t = lane & 31;
+        const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
         const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-        const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 5;
         const float x_time = ms.so[0];
-        for (int64_t i0 = hw & ~(int64_t)1; i0 < a.new_row; i0 += stride) {
-            int64_t i = i0 + (hw & 1);
-            const bool live = i < a.new_row;
-            if (!live) i = a.new_row - 1;
-            const float* ri = a.img + i * RS;
-            const float S = hm_halfwave_sum(d, lane, [&](int e) { return ri[hm_img_off(e)] * ms.so[1 + e]; });
-            const float tp = ri[RS - 4] * x_time;
-            const float mm = tp - S;
-            const float dd = hm::dist_from_u(a.sign_mode ? mm : -mm, a.sqrt_c);
-            if (live && dd < a.thr) {
+        for (int64_t base = (hw & ~(int64_t)1) * 32; base < a.new_row; base += nhw * 32) {
+            const int64_t mybase = base + (hw & 1) * 32;
+            const float u = hm_halfwave_gather32(lane, [&](int k) {
+                const int64_t r = mybase + k < a.new_row ? mybase + k : a.new_row - 1;
+                const float* ri = a.img + r * RS;
+                const float S = hm_halfwave_sum(d, lane, [&](int e) { return ri[hm_img_off(e)] * ms.so[1 + e]; });
+                const float tp = ri[RS - 4] * x_time;
+                const float mm = tp - S;
+                return a.sign_mode ? mm : -mm;
+            });
+            const int64_t i = mybase + t;
+            const float dd = hm::dist_from_u(u, a.sqrt_c);
+            if (i < a.new_row && dd < a.thr) {
                 const uint32_t db = hm::fbits(dd);
                 if (hm_key_less(db, (uint32_t)i, (uint32_t)a.new_row, b0, b1, b2)) { b0 = db; b1 = (uint32_t)i; b2 = (uint32_t)a.new_row; }
             }

@@ -94,25 +94,40 @@ int hm_build_rows(hm_engine* e, const float* X, int64_t ld, int64_t r0, int64_t 
 // ------------------------------------------------------------------------------------------------
 // gathered / one-vs-all distances on the image (half-wave per output, coalesced row reads)
 // ------------------------------------------------------------------------------------------------
+// (each half-wave takes 32 consecutive outputs per round: hm_halfwave_gather32)
 __global__ __launch_bounds__(256) void hm_pairdist_kernel(const float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
                                                           const int32_t* __restrict__ J, int64_t b, float sqrt_c, int sign_mode,
                                                           float* __restrict__ out)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;      // half-wave id = output index
-    const int64_t t = hw < b ? hw : b - 1;                                        // the wave's lanes stay together
-    const float u = hm_img_u_halfwave(img, RS, d, I[t], J[t], sign_mode, lane);
-    if (hw < b && (lane & 31) == 0) out[t] = hm::dist_from_u(u, sqrt_c);
+    const int lane = threadIdx.x & 63, t = lane & 31;
+    const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
+    const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    for (int64_t base = (hw & ~(int64_t)1) * 32; base < b; base += nhw * 32) {      // wave-uniform trip count
+        const int64_t mybase = base + (hw & 1) * 32;
+        const int64_t mine_idx = mybase + t < b ? mybase + t : b - 1;
+        const int32_t my_i = I[mine_idx], my_j = J[mine_idx];
+        const float u = hm_halfwave_gather32(lane, [&](int k) {
+            const int32_t ri = __shfl(my_i, (lane & 32) + k, 64), rj = __shfl(my_j, (lane & 32) + k, 64);
+            return hm_img_u_halfwave(img, RS, d, ri, rj, sign_mode, lane);
+        });
+        if (mybase + t < b) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
+    }
 }
 
 __global__ __launch_bounds__(256) void hm_rowvsall_kernel(const float* __restrict__ img, int RS, int d, int64_t row, int64_t n,
                                                           float sqrt_c, int sign_mode, float* __restrict__ out)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, t = lane & 31;
+    const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
     const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int64_t t = hw < n ? hw : n - 1;
-    const float u = hm_img_u_halfwave(img, RS, d, row, t, sign_mode, lane);
-    if (hw < n && (lane & 31) == 0) out[t] = hm::dist_from_u(u, sqrt_c);
+    for (int64_t base = (hw & ~(int64_t)1) * 32; base < n; base += nhw * 32) {
+        const int64_t mybase = base + (hw & 1) * 32;
+        const float u = hm_halfwave_gather32(lane, [&](int k) {
+            const int64_t r = mybase + k < n ? mybase + k : n - 1;
+            return hm_img_u_halfwave(img, RS, d, row, r, sign_mode, lane);
+        });
+        if (mybase + t < n) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -175,20 +190,25 @@ __global__ __launch_bounds__(256) void hm_coherence_kernel(const float* __restri
 {
     __shared__ MidScratch ms[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5;
-    const int64_t t = (int64_t)blockIdx.x * 4 + wv;
-    if (t >= b) return;
+    const int64_t t0 = (int64_t)blockIdx.x * 4 + wv;
+    if (t0 >= b) return;
     MidScratch& m = ms[wv];
-    hm_wave_stage_rows(img, RS, d, I[t], J[t], m, lane);
-    hm_wave_midpoint(d, W[t], c, sign_mode, m, false, lane);
+    hm_wave_stage_rows(img, RS, d, I[t0], J[t0], m, lane);
+    hm_wave_midpoint(d, W[t0], c, sign_mode, m, false, lane);
     const float m0 = m.so[0];
-    for (int s0 = 0; s0 < ns; s0 += 2) {
-        const int s = s0 + h < ns ? s0 + h : ns - 1;          // both half-waves stay in the loop
-        const float* row = img + (int64_t)S[t * ns + s] * RS;
-        const float Ssum = hm_halfwave_sum(d, lane, [&](int e) { return m.so[1 + e] * row[hm_img_off(e)]; });
-        const float tp = m0 * row[RS - 4];
-        const float mm = tp - Ssum;
-        const float dd = hm::dist_from_u(sign_mode ? mm : -mm, sqrt_c);
-        if (s0 + h < ns && (lane & 31) == 0) out[t * ns + s] = dd;
+    const int t = lane & 31;
+    for (int s0 = 0; s0 < ns; s0 += 64) {                     // a round: half-wave h takes samples s0 + 32 h .. + 31
+        const int sb = s0 + 32 * h;
+        const int my_s = sb + t < ns ? sb + t : ns - 1;
+        const int32_t my_row = S[t0 * ns + my_s];
+        const float u = hm_halfwave_gather32(lane, [&](int k) {
+            const float* row = img + (int64_t)__shfl(my_row, (lane & 32) + k, 64) * RS;
+            const float Ssum = hm_halfwave_sum(d, lane, [&](int e) { return m.so[1 + e] * row[hm_img_off(e)]; });
+            const float tp = m0 * row[RS - 4];
+            const float mm = tp - Ssum;
+            return sign_mode ? mm : -mm;
+        });
+        if (sb + t < ns) out[t0 * ns + sb + t] = hm::dist_from_u(u, sqrt_c);
     }
 }
 
@@ -267,23 +287,23 @@ __device__ __forceinline__ float hm_rm_u_halfwave(const float* x, const float* y
     return sign_mode ? m : -m;
 }
 
-// out[i, j] for a 2 x 32 tile of outputs per wave: half-wave h takes row i = 2 * blockIdx.y' + h ... kept simple:
-// one half-wave per output, outputs enumerated row-major
+// one half-wave per 32 consecutive outputs (row-major enumeration of out[i, j])
 __global__ __launch_bounds__(256) void hm_dense_kernel(const float* __restrict__ X, int64_t n1, const float* __restrict__ Y, int64_t n2,
                                                        int64_t ldx, int64_t ldy, int d1, float sqrt_c, int sign_mode,
                                                        float* __restrict__ out)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, t = lane & 31;
     const int64_t total = n1 * n2;
-    const int64_t hw0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int64_t step = ((int64_t)gridDim.x * blockDim.x) >> 5;
-    const int64_t rounds = (total + step - 1) / step;
-    for (int64_t r = 0; r < rounds; ++r) {
-        const int64_t o = hw0 + r * step;
-        const int64_t t = o < total ? o : total - 1;
-        const int64_t i = t / n2, j = t - i * n2;
-        const float u = hm_rm_u_halfwave(X + i * ldx, Y + j * ldy, d1, sign_mode, lane);
-        if (o < total && (lane & 31) == 0) out[t] = hm::dist_from_u(u, sqrt_c);
+    const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
+    const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    for (int64_t base = (hw & ~(int64_t)1) * 32; base < total; base += nhw * 32) {
+        const int64_t mybase = base + (hw & 1) * 32;
+        const float u = hm_halfwave_gather32(lane, [&](int k) {
+            const int64_t o = mybase + k < total ? mybase + k : total - 1;
+            const int64_t i = o / n2, j = o - i * n2;
+            return hm_rm_u_halfwave(X + i * ldx, Y + j * ldy, d1, sign_mode, lane);
+        });
+        if (mybase + t < total) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
     }
 }
 
@@ -299,11 +319,17 @@ __global__ void hm_rows_minkowski_kernel(const float* __restrict__ x, const floa
 __global__ __launch_bounds__(256) void hm_rows_distance_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t b, int64_t ld,
                                                                int d1, float sqrt_c, int sign_mode, float* __restrict__ out)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, t = lane & 31;
+    const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
     const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int64_t t = hw < b ? hw : b - 1;
-    const float u = hm_rm_u_halfwave(x + t * ld, y + t * ld, d1, sign_mode, lane);
-    if (hw < b && (lane & 31) == 0) out[t] = hm::dist_from_u(u, sqrt_c);
+    for (int64_t base = (hw & ~(int64_t)1) * 32; base < b; base += nhw * 32) {
+        const int64_t mybase = base + (hw & 1) * 32;
+        const float u = hm_halfwave_gather32(lane, [&](int k) {
+            const int64_t r = mybase + k < b ? mybase + k : b - 1;
+            return hm_rm_u_halfwave(x + r * ld, y + r * ld, d1, sign_mode, lane);
+        });
+        if (mybase + t < b) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
+    }
 }
 
 __global__ void hm_rows_log_map_kernel(const float* __restrict__ x, const float* __restrict__ y, int64_t b, int64_t ld, int d1,
@@ -359,7 +385,7 @@ extern "C" int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, floa
         return hm_fail(e, HM_E_ARG, "hm_row_vs_all: bad arguments");
     HM_HIP(hipSetDevice(e->device));
     if (n == 0) return HM_OK;
-    hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+    hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
                        row, n, sqrtf(c), e->sign_mode, d_out_dev);
     HM_HIP(hipGetLastError());
     return HM_OK;
@@ -372,7 +398,7 @@ extern "C" int hm_pair_distance(hm_engine* e, const int32_t* I_dev, const int32_
     if (b < 0 || (b > 0 && (!I_dev || !J_dev || !out_dev)) || !(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pair_distance: bad arguments");
     HM_HIP(hipSetDevice(e->device));
     if (b == 0) return HM_OK;
-    hipLaunchKernelGGL(hm_pairdist_kernel, dim3((unsigned)((b + 7) / 8)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+    hipLaunchKernelGGL(hm_pairdist_kernel, dim3((unsigned)std::min<int64_t>((b + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
                        I_dev, J_dev, b, sqrtf(c), e->sign_mode, out_dev);
     HM_HIP(hipGetLastError());
     return HM_OK;
@@ -475,7 +501,7 @@ extern "C" int hm_batch_distance(const float* X_dev, int64_t n1, const float* Y_
     if (n1 == 0 || n2 == 0) return HM_OK;
     if (!X_dev || !Y_dev || !out_dev) return hm_fail(nullptr, HM_E_ARG, "hm_batch_distance: NULL pointer");
     const int64_t total = n1 * n2;
-    const unsigned blocks = (unsigned)std::min<int64_t>((total + 7) / 8, 8192);
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(hm_dense_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X_dev, n1, Y_dev, n2, ld_x, ld_y, d1,
                        sqrtf(c), sign_mode, out_dev);
     HM_HIP0(hipGetLastError());
@@ -498,7 +524,7 @@ extern "C" int hm_rows_distance(const float* x_dev, const float* y_dev, int64_t 
 {
     if (b < 0 || d1 < 2 || ld < d1 || !(c > 0.0f)) return hm_fail(nullptr, HM_E_ARG, "hm_rows_distance: bad arguments");
     if (b == 0) return HM_OK;
-    hipLaunchKernelGGL(hm_rows_distance_kernel, dim3((unsigned)((b + 7) / 8)), dim3(256), 0, (hipStream_t)stream, x_dev, y_dev, b,
+    hipLaunchKernelGGL(hm_rows_distance_kernel, dim3((unsigned)std::min<int64_t>((b + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, x_dev, y_dev, b,
                        ld, d1, sqrtf(c), sign_mode, out_dev);
     HM_HIP0(hipGetLastError());
     return HM_OK;

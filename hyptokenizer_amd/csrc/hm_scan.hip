@@ -591,7 +591,9 @@ static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, h
         if (it == e->occupancy.end()) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WPB, lds) != hipSuccess || per_cu < 1) per_cu = 1;
             e->occupancy[fn] = per_cu;
+            if (getenv("HM_TUNE_VERBOSE")) fprintf(stderr, "[hypmerge] scan kernel TM=%d WPB=%d lds=%zu: %d resident block(s) per CU, %d CUs\n", TM, WPB, lds, per_cu, e->n_cu);
         } else per_cu = it->second;
+        if (e->persist > 1) per_cu = e->persist - 1;                      // HM_TUNE_PERSIST = 1 + blocks per CU: override
         const long long resident = (long long)e->n_cu * per_cu;
         grid = dim3((unsigned)std::max<long long>(1, std::min(resident, b.p_total / 4)), 1, 1);
     }

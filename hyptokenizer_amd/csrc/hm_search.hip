@@ -48,22 +48,27 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
     }
     const unsigned long long emitted = a.ctr64[2];
     const uint32_t m = emitted > (unsigned long long)a.cap ? a.cap : (uint32_t)emitted;
-    uint32_t active = (m + HM_TAIL_SOLO - 1) / HM_TAIL_SOLO;
+    uint32_t active = (m + HM_TAIL_SOLO - 1) / HM_TAIL_SOLO;       // HM_TAIL_SOLO = entries one block takes per two rounds
     if (active < 1) active = 1;
     if (active > gridDim.x) active = gridDim.x;
     if (blockIdx.x >= active) return;
 
     // ---- exact distance of this block's entries, lexicographic min of (d bits, i, j) with d < thr ----
     uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
+    // a half-wave takes 32 consecutive entries per round (hm_halfwave_gather32): lane t finishes entry t
     const uint32_t hw = (blockIdx.x * HM_TAIL_THREADS + threadIdx.x) >> 5;          // half-wave id
-    const uint32_t stride = active * (HM_TAIL_THREADS >> 5);
-    const uint32_t hw_wave0 = hw & ~1u;                                             // first half-wave of this wave
-    for (uint32_t t0 = hw_wave0; t0 < m; t0 += stride) {                            // wave-uniform trip count
-        const uint32_t t = t0 + (hw & 1u);
-        const uint4 en = a.ent[t < m ? t : m - 1];
-        const float u = hm_img_u_halfwave(a.img, a.RS, a.d, en.y, en.z, a.sign_mode, lane);
+    const uint32_t stride = active * (HM_TAIL_THREADS >> 5) * 32u;
+    const int t32 = lane & 31;
+    for (uint32_t base = (hw & ~1u) * 32u; base < m; base += stride) {             // wave-uniform trip count
+        const uint32_t mybase = base + (hw & 1u) * 32u;
+        const uint32_t mine = mybase + t32;
+        const uint4 en = a.ent[mine < m ? mine : m - 1];
+        const float u = hm_halfwave_gather32(lane, [&](int k) {
+            const uint32_t ri = __shfl(en.y, (lane & 32) + k, 64), rj = __shfl(en.z, (lane & 32) + k, 64);
+            return hm_img_u_halfwave(a.img, a.RS, a.d, ri, rj, a.sign_mode, lane);
+        });
         const float dd = hm::dist_from_u(u, a.sqrt_c);
-        if (t < m && dd < a.thr) {
+        if (mine < m && dd < a.thr) {
             const uint32_t db = hm::fbits(dd);
             if (hm_key_less(db, en.y, en.z, b0, b1, b2)) { b0 = db; b1 = en.y; b2 = en.z; }
         }
@@ -200,39 +205,17 @@ __device__ __forceinline__ void hm_rowpass_block(const float* __restrict__ img, 
                                                  int64_t n_partners, float sqrt_c, float thr, uint32_t& b0, uint32_t& b1, uint32_t& b2)
 {
     const int lane = threadIdx.x & 63, t = lane & 31;
-    const float* rr = img + row * RS;
-    // the row's elements this lane multiplies: main chains, leftover vector, tail, time
-    const int vec = d >> 3, ilp = vec >> 2, nleft = vec - ilp * 4, ntail = d - vec * 8;
-    float x_main[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < ilp) x_main[i] = rr[hm_img_off(i * 32 + t)];
-    const int e_left = (ilp * 4 + (t >> 3)) * 8 + (t & 7);
-    const float x_left = (d >= 8 && (t >> 3) < nleft) ? rr[hm_img_off(e_left)] : 0.0f;
-    const float x_tail = (d >= 8 && t < ntail) ? rr[hm_img_off(vec * 8 + t)] : 0.0f;
-    const float x_time = rr[RS - 4];
+    const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
     const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 5;
-    const int64_t hw0 = hw & ~(int64_t)1;
-    for (int64_t i0 = hw0; i0 < n_partners; i0 += stride) {
-        int64_t i = i0 + (hw & 1);
-        const bool live = i < n_partners && i != row;
-        if (i >= n_partners) i = n_partners - 1;
-        const float* ri = img + i * RS;
-        float S;
-        if (d >= 8) {
-            S = hm_halfwave_sum(d, lane, [&](int e) {
-                // the sum asks each lane for exactly the elements cached above
-                const float xv = e < ilp * 32 ? x_main[e >> 5] : (e < vec * 8 ? x_left : x_tail);
-                return xv * ri[hm_img_off(e)];
-            });
-        } else {
-            S = hm_halfwave_sum(d, lane, [&](int e) { return rr[hm_img_off(e)] * ri[hm_img_off(e)]; });
-        }
-        const float tp = x_time * ri[RS - 4];
-        const float mm = tp - S;
-        const float dd = hm::dist_from_u(sign_mode ? mm : -mm, sqrt_c);
-        if (live && dd < thr) {
+    for (int64_t base = (hw & ~(int64_t)1) * 32; base < n_partners; base += nhw * 32) {
+        const int64_t mybase = base + (hw & 1) * 32;
+        const float u = hm_halfwave_gather32(lane, [&](int k) {
+            const int64_t r = mybase + k < n_partners ? mybase + k : n_partners - 1;
+            return hm_img_u_halfwave(img, RS, d, row, r, sign_mode, lane);
+        });
+        const int64_t i = mybase + t;
+        const float dd = hm::dist_from_u(u, sqrt_c);
+        if (i < n_partners && i != row && dd < thr) {
             const uint32_t lo = (uint32_t)(i < row ? i : row), hi = (uint32_t)(i < row ? row : i);
             const uint32_t db = hm::fbits(dd);
             if (hm_key_less(db, lo, hi, b0, b1, b2)) { b0 = db; b1 = lo; b2 = hi; }
@@ -295,14 +278,19 @@ __global__ __launch_bounds__(256) void hm_post_distance_kernel(uint4* __restrict
     const int lane = threadIdx.x & 63;
     uint32_t nv = 0, nb = 0, bad = 0, nc = 0;
     const uint32_t hw = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const uint32_t stride = (gridDim.x * blockDim.x) >> 5;
-    for (uint32_t t0 = hw & ~1u; t0 < m; t0 += stride) {
-        const uint32_t t = t0 + (hw & 1u);
-        const uint4 en = ent[t < m ? t : m - 1];
-        const float u = hm_img_u_halfwave(img, RS, d, en.y, en.z, sign_mode, lane);
+    const uint32_t stride = ((gridDim.x * blockDim.x) >> 5) * 32u;
+    const int t32 = lane & 31;
+    for (uint32_t base = (hw & ~1u) * 32u; base < m; base += stride) {
+        const uint32_t mybase = base + (hw & 1u) * 32u;
+        const uint32_t mine = mybase + t32;
+        const uint4 en = ent[mine < m ? mine : m - 1];
+        const float u = hm_halfwave_gather32(lane, [&](int k) {
+            const uint32_t ri = __shfl(en.y, (lane & 32) + k, 64), rj = __shfl(en.z, (lane & 32) + k, 64);
+            return hm_img_u_halfwave(img, RS, d, ri, rj, sign_mode, lane);
+        });
         const float uc = hm::clamp_min_one(u);
         const float dd = hm::acosh_c(uc) / sqrt_c;
-        if (t < m && (lane & 31) == 0) {
+        if (mine < m) {
             const bool valid = dd < thr;
             nv += valid ? 1u : 0u;
             nb += (valid && en.w == 0u) ? 1u : 0u;
@@ -312,7 +300,7 @@ __global__ __launch_bounds__(256) void hm_post_distance_kernel(uint4* __restrict
             const bool complete = tie_imax != 0x7fffffff ? (zero && (int)en.y <= tie_imax)
                                                          : (zero || (cut_bits != 0xffffffffu ? (ub + HM_TIE_SLACK <= cut_bits) : true));
             nc += (valid && complete) ? 1u : 0u;
-            ent[t] = make_uint4(valid ? hm::fbits(dd) : 0xffffffffu, en.y, en.z, ub);
+            ent[mine] = make_uint4(valid ? hm::fbits(dd) : 0xffffffffu, en.y, en.z, ub);
         }
     }
 #pragma unroll
