@@ -75,7 +75,7 @@ def load() -> C.CDLL:
     L.hm_set_prefilter.argtypes = [vp, C.c_int]
     L.hm_pairwise_topk_nocount.argtypes = [vp, f32, f32, i64, i64, i64, vp, vp, vp, pi64, pi64, vp]
     L.hm_pairwise_count.argtypes = [vp, f32, f32, i64, pi64, vp]
-    L.hm_merge_append_batch.argtypes = [vp, vp, vp, vp, i64, f32, vp, i64, i64, vp]
+    L.hm_merge_append_batch.argtypes = [vp, vp, vp, vp, i64, f32, vp, i64, i64, C.c_int, vp]
     L.hm_truncate.argtypes = [vp, i64, vp]
     L.hm_set_token_lengths.argtypes = [vp, vp, i64, vp]
     L.hm_std_merge_steps.argtypes = [vp, f32, f32, vp, i64, i64, vp, pi64, vp]

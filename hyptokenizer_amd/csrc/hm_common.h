@@ -50,7 +50,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_RANK_LIMIT 49152        // rank sort is O(M^2): narrow by radix digits above this
 #define HM_TAIL_BLOCKS 32          // blocks of the argmin tail kernel (one is enough for <= HM_TAIL_SOLO entries)
 #define HM_TAIL_THREADS 1024
-#define HM_TAIL_SOLO 2048u
+#define HM_TAIL_SOLO 1024u
 #define HM_ROWPASS_BLOCKS 256      // blocks of the one-row-vs-all reduction
 #define HM_PART_SLOTS 256          // partial records (>= HM_TAIL_BLOCKS, HM_ROWPASS_BLOCKS)
 #define HM_LOOP_MAX_STEPS 64       // steps one device-resident loop call may enqueue
@@ -122,9 +122,11 @@ struct HostCtl {                 // pinned host mirror of small device results
 struct LoopState {
     uint32_t stop;               // 0 running, 1 no candidate, 2 emission overflow
     uint32_t steps_done;
-    ArgminRec best;              // incremental loop: running nearest pair
-    uint32_t ticket;             // last-block ticket of the row pass
-    uint32_t pad[3];
+    ArgminRec best;              // incremental loop: running nearest pair (as of the start of the last executed step)
+    uint32_t pad[2];
+    // incremental loop: nearest partner of the row appended by step k, folded in by every block with one 64-bit
+    // atomicMin: (bits(d) << 32) | i  (the partner is always paired with that new row); all ones = none
+    unsigned long long rowkey[HM_LOOP_MAX_STEPS];
 };
 
 struct hm_engine {
@@ -317,16 +319,19 @@ __device__ __forceinline__ float hm_img_u_halfwave(const float* img, int RS, int
     return sign_mode ? m : -m;
 }
 
-// A half-wave works through 32 items: item k's canonical u is computed by the 32 lanes together (u_of(k) returns it on
-// every lane; both half-waves of the wave call in step, each for its own item k) and parked in lane k.  The caller then
-// finishes ITS item once -- acosh, threshold, key -- in parallel over the lanes instead of 32 times redundantly.
+// A half-wave works through HM_GATHER items per round: item k's canonical u is computed by the 32 lanes together
+// (u_of(k) returns it on every lane; both half-waves of the wave call in step, each for its own item k) and parked in
+// lane k.  The caller then finishes ITS item once -- acosh, threshold, key -- so the transcendental part is evaluated once
+// per HM_GATHER items instead of once per item (every lane executes it either way).  Few items per round on purpose:
+// the rounds of different half-waves are what hides the L2 latency of the row reads (32 per round measured 2.4x slower).
+#define HM_GATHER 8
 template <class UF>
-__device__ __forceinline__ float hm_halfwave_gather32(int lane, UF u_of)
+__device__ __forceinline__ float hm_halfwave_gather(int lane, UF u_of)
 {
     const int t = lane & 31;
     float mine = 0.0f;
-#pragma unroll 4
-    for (int k = 0; k < 32; ++k) {
+#pragma unroll
+    for (int k = 0; k < HM_GATHER; ++k) {
         const float u = u_of(k);
         mine = (t == k) ? u : mine;
     }

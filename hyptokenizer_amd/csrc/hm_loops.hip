@@ -136,20 +136,30 @@ struct IncrArgs {
     int64_t new_row;             // = partners [0, new_row)
     int32_t* len;
     LoopState* loop;
-    ArgminPart* parts;
     ArgminRec* rec_ring;         // this step's record
     uint32_t* rmax2_bits;
+    int step;                    // index inside the batch
 };
 
+// One launch per merge, no inter-block hand-off inside it: every block (1) folds the previous step's row pass into the
+// running minimum -- the same few loads and compares in every block --, (2) recomputes the merged row (wave 0; block 0
+// also stores it and writes the step's record), (3) scans its slice of the image against the new row and publishes its
+// nearest partner with ONE 64-bit atomicMin.  The fold of THIS step's row pass happens at the start of the next launch
+// (or on the host after the last one), so there is no ticket, no fence and no final block.
 __global__ __launch_bounds__(512) void hm_incr_step_kernel(const IncrArgs a)
 {
-    __shared__ uint32_t s0[8], s1[8], s2[8];
-    __shared__ uint32_t s_last;
     __shared__ MidScratch ms;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     LoopState* loop = a.loop;
     const uint32_t stop = loop->stop;
-    const ArgminRec best = loop->best;
+    ArgminRec best = loop->best;
+    if (a.step > 0 && stop == 0u) {
+        const unsigned long long rk = loop->rowkey[a.step - 1];        // complete: the previous launch has ended
+        if (rk != ~0ull) {
+            const uint32_t db = (uint32_t)(rk >> 32), ri = (uint32_t)rk, rj = (uint32_t)(a.new_row - 1);
+            if (best.found != 1u || hm_key_less(db, ri, rj, best.dbits, best.i, best.j)) { best.found = 1u; best.dbits = db; best.i = ri; best.j = rj; }
+        }
+    }
     if (stop != 0u || best.found != 1u) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             ArgminRec r; r.found = stop != 0u ? 3u : 0u; r.dbits = 0; r.i = 0xffffffffu; r.j = 0xffffffffu;
@@ -169,21 +179,22 @@ __global__ __launch_bounds__(512) void hm_incr_step_kernel(const IncrArgs a)
             if (lane == 0) {
                 a.len[a.new_row] = li + lj;
                 *a.rec_ring = best;                        // the pair this step merged
+                loop->best = best;                         // the running minimum as of this step's start
                 loop->steps_done += 1u;
             }
         }
     }
     __syncthreads();
     // ---- nearest partner of the new row among rows [0, new_row): a half-wave per partner row ----
-    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
+    unsigned long long key = ~0ull;
     {
         const int d = a.d, RS = a.RS, t = lane & 31;
         const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
         const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
         const float x_time = ms.so[0];
-        for (int64_t base = (hw & ~(int64_t)1) * 32; base < a.new_row; base += nhw * 32) {
-            const int64_t mybase = base + (hw & 1) * 32;
-            const float u = hm_halfwave_gather32(lane, [&](int k) {
+        for (int64_t base = (hw & ~(int64_t)1) * HM_GATHER; base < a.new_row; base += nhw * HM_GATHER) {
+            const int64_t mybase = base + (hw & 1) * HM_GATHER;
+            const float u = hm_halfwave_gather(lane, [&](int k) {
                 const int64_t r = mybase + k < a.new_row ? mybase + k : a.new_row - 1;
                 const float* ri = a.img + r * RS;
                 const float S = hm_halfwave_sum(d, lane, [&](int e) { return ri[hm_img_off(e)] * ms.so[1 + e]; });
@@ -193,40 +204,14 @@ __global__ __launch_bounds__(512) void hm_incr_step_kernel(const IncrArgs a)
             });
             const int64_t i = mybase + t;
             const float dd = hm::dist_from_u(u, a.sqrt_c);
-            if (i < a.new_row && dd < a.thr) {
-                const uint32_t db = hm::fbits(dd);
-                if (hm_key_less(db, (uint32_t)i, (uint32_t)a.new_row, b0, b1, b2)) { b0 = db; b1 = (uint32_t)i; b2 = (uint32_t)a.new_row; }
+            if (t < HM_GATHER && i < a.new_row && dd < a.thr) {
+                const unsigned long long k64 = ((unsigned long long)hm::fbits(dd) << 32) | (unsigned long long)(uint32_t)i;
+                key = k64 < key ? k64 : key;
             }
         }
     }
-    hm_block_min_key(b0, b1, b2, s0, s1, s2);
-    if (threadIdx.x == 0) {
-        ArgminPart pt; pt.dbits = b0; pt.i = b1; pt.j = b2; pt.pad = 0;
-        a.parts[blockIdx.x] = pt;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t tk = __hip_atomic_fetch_add(&loop->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (tk == gridDim.x - 1) ? 1u : 0u;
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            loop->ticket = 0u;
-        }
-    }
-    __syncthreads();
-    if (s_last == 0u) return;
-    b0 = b1 = b2 = 0xffffffffu;
-    if (threadIdx.x < gridDim.x) {
-        const ArgminPart pt = a.parts[threadIdx.x];
-        b0 = pt.dbits; b1 = pt.i; b2 = pt.j;
-    }
-    hm_block_min_key(b0, b1, b2, s0, s1, s2);
-    if (threadIdx.x == 0) {
-        // running minimum: the pair just merged still exists (rows are never removed) and stays a candidate
-        ArgminRec nb = best;
-        if (b1 != 0xffffffffu && hm_key_less(b0, b1, b2, best.dbits, best.i, best.j)) { nb.dbits = b0; nb.i = b1; nb.j = b2; }
-        loop->best = nb;
-    }
+    key = hm_wave_min_u64(key);
+    if (lane == 0 && key != ~0ull) atomicMin(&loop->rowkey[a.step], key);
 }
 
 // K steps of the incremental loop.  best_*: the current nearest pair (from a full search); on return the
@@ -250,22 +235,40 @@ extern "C" int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_de
     st.best.found = best_io[0]; st.best.dbits = best_io[1]; st.best.i = best_io[2]; st.best.j = best_io[3];
     memcpy(&e->h->rec2[0], &st.best, sizeof(ArgminRec));
     HM_HIP(hipMemsetAsync(e->d_loop, 0, sizeof(LoopState), s));
+    HM_HIP(hipMemsetAsync(e->d_loop->rowkey, 0xff, sizeof(unsigned long long) * HM_LOOP_MAX_STEPS, s));
     HM_HIP(hipMemcpyAsync(&e->d_loop->best, &e->h->rec2[0], sizeof(ArgminRec), hipMemcpyHostToDevice, s));
     IncrArgs a;
     a.img = e->img; a.img16 = e->img16; a.RS = e->RS; a.d = e->d; a.KS = e->KS; a.sign_mode = e->sign_mode;
     a.c = c; a.sqrt_c = sqrtf(c); a.thr = thr; a.X = X_dev; a.ld = ld; a.len = e->d_len; a.loop = e->d_loop;
-    a.parts = e->d_parts; a.rmax2_bits = e->d_rmax2;
+    a.rmax2_bits = e->d_rmax2;
     for (int64_t k = 0; k < steps; ++k) {
         a.new_row = n0 + k;
+        a.step = (int)k;
         a.rec_ring = e->d_loop_recs + k;
         hipLaunchKernelGGL(hm_incr_step_kernel, dim3(HM_ROWPASS_BLOCKS), dim3(512), 0, s, a);
         HM_HIP(hipGetLastError());
     }
     HM_HIP(hipMemcpyAsync(e->h->loop_recs, e->d_loop_recs, sizeof(ArgminRec) * (size_t)steps, hipMemcpyDeviceToHost, s));
     HM_HIP(hipMemcpyAsync(&e->h->rec, &e->d_loop->best, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
+    HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_loop->rowkey + (steps - 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HM_HIP(hipStreamSynchronize(s));
     hm_unpack_recs(e->h->loop_recs, steps, rec_out, done);
-    best_io[0] = e->h->rec.found; best_io[1] = e->h->rec.dbits; best_io[2] = e->h->rec.i; best_io[3] = e->h->rec.j;
+    // the running minimum after the last executed step: its start-of-step value folded with that step's row pass
+    // (when the batch ran to its end; an earlier stop means the minimum did not exist: found = 0)
+    ArgminRec fin = e->h->rec;
+    if (*done == steps) {
+        const unsigned long long rk = e->h->ctr64[0];
+        if (rk != ~0ull) {
+            const uint32_t db = (uint32_t)(rk >> 32), ri = (uint32_t)rk, rj = (uint32_t)(n0 + steps - 1);
+            const bool less = fin.found != 1u || db < fin.dbits || (db == fin.dbits && (ri < fin.i || (ri == fin.i && rj < fin.j)));
+            if (less) { fin.found = 1u; fin.dbits = db; fin.i = ri; fin.j = rj; }
+        }
+    } else if (*done < steps) {
+        // the loop stopped at step *done: the fold of step *done - 1's row pass was made by that launch's blocks; what it
+        // found (nothing below the threshold) is what stopped the loop
+        fin.found = 0u;
+    }
+    best_io[0] = fin.found; best_io[1] = fin.dbits; best_io[2] = fin.i; best_io[3] = fin.j;
     e->n = n0 + *done;
     return HM_OK;
 }

@@ -102,15 +102,15 @@ __global__ __launch_bounds__(256) void hm_pairdist_kernel(const float* __restric
     const int lane = threadIdx.x & 63, t = lane & 31;
     const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
     const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    for (int64_t base = (hw & ~(int64_t)1) * 32; base < b; base += nhw * 32) {      // wave-uniform trip count
-        const int64_t mybase = base + (hw & 1) * 32;
+    for (int64_t base = (hw & ~(int64_t)1) * HM_GATHER; base < b; base += nhw * HM_GATHER) {      // wave-uniform trip count
+        const int64_t mybase = base + (hw & 1) * HM_GATHER;
         const int64_t mine_idx = mybase + t < b ? mybase + t : b - 1;
         const int32_t my_i = I[mine_idx], my_j = J[mine_idx];
-        const float u = hm_halfwave_gather32(lane, [&](int k) {
+        const float u = hm_halfwave_gather(lane, [&](int k) {
             const int32_t ri = __shfl(my_i, (lane & 32) + k, 64), rj = __shfl(my_j, (lane & 32) + k, 64);
             return hm_img_u_halfwave(img, RS, d, ri, rj, sign_mode, lane);
         });
-        if (mybase + t < b) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
+        if (t < HM_GATHER && mybase + t < b) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
     }
 }
 
@@ -120,13 +120,13 @@ __global__ __launch_bounds__(256) void hm_rowvsall_kernel(const float* __restric
     const int lane = threadIdx.x & 63, t = lane & 31;
     const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
     const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    for (int64_t base = (hw & ~(int64_t)1) * 32; base < n; base += nhw * 32) {
-        const int64_t mybase = base + (hw & 1) * 32;
-        const float u = hm_halfwave_gather32(lane, [&](int k) {
+    for (int64_t base = (hw & ~(int64_t)1) * HM_GATHER; base < n; base += nhw * HM_GATHER) {
+        const int64_t mybase = base + (hw & 1) * HM_GATHER;
+        const float u = hm_halfwave_gather(lane, [&](int k) {
             const int64_t r = mybase + k < n ? mybase + k : n - 1;
             return hm_img_u_halfwave(img, RS, d, row, r, sign_mode, lane);
         });
-        if (mybase + t < n) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
+        if (t < HM_GATHER && mybase + t < n) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
     }
 }
 
@@ -177,6 +177,22 @@ __global__ __launch_bounds__(64) void hm_merge_batch_kernel(float* __restrict__ 
     }
 }
 
+// the same batch when no merge reads a row the batch writes (every operand row < first_row -- the fast tokenizer's case:
+// cached candidates only name rows that existed at the refresh): one wave per merge, all at once
+__global__ __launch_bounds__(256) void hm_merge_rows_kernel(float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
+                                                            const int32_t* __restrict__ J, const float* __restrict__ W, int count, float c,
+                                                            int sign_mode, float* __restrict__ X, int64_t ld, int64_t first_row,
+                                                            uint32_t* __restrict__ rmax2_bits, unsigned char* __restrict__ img16, int KS)
+{
+    __shared__ MidScratch ms[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wv;
+    if (t >= count) return;
+    hm_wave_stage_rows(img, RS, d, I[t], J[t], ms[wv], lane);
+    const float r2 = hm_wave_midpoint(d, W[t], c, sign_mode, ms[wv], true, lane);
+    hm_wave_store_row(ms[wv], r2, d, RS, KS, X, ld, img, img16, first_row + t, rmax2_bits, lane);
+}
+
 // ------------------------------------------------------------------------------------------------
 // enhanced tokenizer (BASELINE config 5)
 // ------------------------------------------------------------------------------------------------
@@ -197,18 +213,18 @@ __global__ __launch_bounds__(256) void hm_coherence_kernel(const float* __restri
     hm_wave_midpoint(d, W[t0], c, sign_mode, m, false, lane);
     const float m0 = m.so[0];
     const int t = lane & 31;
-    for (int s0 = 0; s0 < ns; s0 += 64) {                     // a round: half-wave h takes samples s0 + 32 h .. + 31
-        const int sb = s0 + 32 * h;
+    for (int s0 = 0; s0 < ns; s0 += 2 * HM_GATHER) {          // a round: half-wave h takes HM_GATHER samples from s0 + HM_GATHER * h
+        const int sb = s0 + HM_GATHER * h;
         const int my_s = sb + t < ns ? sb + t : ns - 1;
         const int32_t my_row = S[t0 * ns + my_s];
-        const float u = hm_halfwave_gather32(lane, [&](int k) {
+        const float u = hm_halfwave_gather(lane, [&](int k) {
             const float* row = img + (int64_t)__shfl(my_row, (lane & 32) + k, 64) * RS;
             const float Ssum = hm_halfwave_sum(d, lane, [&](int e) { return m.so[1 + e] * row[hm_img_off(e)]; });
             const float tp = m0 * row[RS - 4];
             const float mm = tp - Ssum;
             return sign_mode ? mm : -mm;
         });
-        if (sb + t < ns) out[t0 * ns + sb + t] = hm::dist_from_u(u, sqrt_c);
+        if (t < HM_GATHER && sb + t < ns) out[t0 * ns + sb + t] = hm::dist_from_u(u, sqrt_c);
     }
 }
 
@@ -296,14 +312,14 @@ __global__ __launch_bounds__(256) void hm_dense_kernel(const float* __restrict__
     const int64_t total = n1 * n2;
     const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
     const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    for (int64_t base = (hw & ~(int64_t)1) * 32; base < total; base += nhw * 32) {
-        const int64_t mybase = base + (hw & 1) * 32;
-        const float u = hm_halfwave_gather32(lane, [&](int k) {
+    for (int64_t base = (hw & ~(int64_t)1) * HM_GATHER; base < total; base += nhw * HM_GATHER) {
+        const int64_t mybase = base + (hw & 1) * HM_GATHER;
+        const float u = hm_halfwave_gather(lane, [&](int k) {
             const int64_t o = mybase + k < total ? mybase + k : total - 1;
             const int64_t i = o / n2, j = o - i * n2;
             return hm_rm_u_halfwave(X + i * ldx, Y + j * ldy, d1, sign_mode, lane);
         });
-        if (mybase + t < total) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
+        if (t < HM_GATHER && mybase + t < total) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
     }
 }
 
@@ -322,13 +338,13 @@ __global__ __launch_bounds__(256) void hm_rows_distance_kernel(const float* __re
     const int lane = threadIdx.x & 63, t = lane & 31;
     const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
     const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    for (int64_t base = (hw & ~(int64_t)1) * 32; base < b; base += nhw * 32) {
-        const int64_t mybase = base + (hw & 1) * 32;
-        const float u = hm_halfwave_gather32(lane, [&](int k) {
+    for (int64_t base = (hw & ~(int64_t)1) * HM_GATHER; base < b; base += nhw * HM_GATHER) {
+        const int64_t mybase = base + (hw & 1) * HM_GATHER;
+        const float u = hm_halfwave_gather(lane, [&](int k) {
             const int64_t r = mybase + k < b ? mybase + k : b - 1;
             return hm_rm_u_halfwave(x + r * ld, y + r * ld, d1, sign_mode, lane);
         });
-        if (mybase + t < b) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
+        if (t < HM_GATHER && mybase + t < b) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
     }
 }
 
@@ -385,7 +401,7 @@ extern "C" int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, floa
         return hm_fail(e, HM_E_ARG, "hm_row_vs_all: bad arguments");
     HM_HIP(hipSetDevice(e->device));
     if (n == 0) return HM_OK;
-    hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+    hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)std::min<int64_t>((n + 8 * HM_GATHER - 1) / (8 * HM_GATHER), 8192)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
                        row, n, sqrtf(c), e->sign_mode, d_out_dev);
     HM_HIP(hipGetLastError());
     return HM_OK;
@@ -398,7 +414,7 @@ extern "C" int hm_pair_distance(hm_engine* e, const int32_t* I_dev, const int32_
     if (b < 0 || (b > 0 && (!I_dev || !J_dev || !out_dev)) || !(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pair_distance: bad arguments");
     HM_HIP(hipSetDevice(e->device));
     if (b == 0) return HM_OK;
-    hipLaunchKernelGGL(hm_pairdist_kernel, dim3((unsigned)std::min<int64_t>((b + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+    hipLaunchKernelGGL(hm_pairdist_kernel, dim3((unsigned)std::min<int64_t>((b + 8 * HM_GATHER - 1) / (8 * HM_GATHER), 8192)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
                        I_dev, J_dev, b, sqrtf(c), e->sign_mode, out_dev);
     HM_HIP(hipGetLastError());
     return HM_OK;
@@ -442,7 +458,7 @@ extern "C" int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, floa
 }
 
 extern "C" int hm_merge_append_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev, int64_t count,
-                                     float c, float* X_dev, int64_t ld, int64_t first_row, void* stream)
+                                     float c, float* X_dev, int64_t ld, int64_t first_row, int independent, void* stream)
 {
     if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_merge_append_batch: engine is NULL");
     if (count < 0 || (count > 0 && (!I_dev || !J_dev || !W_dev || !X_dev)) || ld < e->d1 || first_row < 0 ||
@@ -450,8 +466,12 @@ extern "C" int hm_merge_append_batch(hm_engine* e, const int32_t* I_dev, const i
         return hm_fail(e, HM_E_ARG, "hm_merge_append_batch: bad arguments");
     HM_HIP(hipSetDevice(e->device));
     if (count == 0) return HM_OK;
-    hipLaunchKernelGGL(hm_merge_batch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d, I_dev, J_dev, W_dev,
-                       (int)count, c, e->sign_mode, X_dev, ld, first_row, e->d_rmax2, e->img16, e->KS);
+    if (independent)
+        hipLaunchKernelGGL(hm_merge_rows_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
+                           I_dev, J_dev, W_dev, (int)count, c, e->sign_mode, X_dev, ld, first_row, e->d_rmax2, e->img16, e->KS);
+    else
+        hipLaunchKernelGGL(hm_merge_batch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d, I_dev, J_dev, W_dev,
+                           (int)count, c, e->sign_mode, X_dev, ld, first_row, e->d_rmax2, e->img16, e->KS);
     HM_HIP(hipGetLastError());
     hm_rows_changed(e, first_row, (hipStream_t)stream);
     if (first_row + count > e->n) e->n = first_row + count;
@@ -501,7 +521,7 @@ extern "C" int hm_batch_distance(const float* X_dev, int64_t n1, const float* Y_
     if (n1 == 0 || n2 == 0) return HM_OK;
     if (!X_dev || !Y_dev || !out_dev) return hm_fail(nullptr, HM_E_ARG, "hm_batch_distance: NULL pointer");
     const int64_t total = n1 * n2;
-    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 8 * HM_GATHER - 1) / (8 * HM_GATHER), 8192);
     hipLaunchKernelGGL(hm_dense_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X_dev, n1, Y_dev, n2, ld_x, ld_y, d1,
                        sqrtf(c), sign_mode, out_dev);
     HM_HIP0(hipGetLastError());
@@ -524,7 +544,7 @@ extern "C" int hm_rows_distance(const float* x_dev, const float* y_dev, int64_t 
 {
     if (b < 0 || d1 < 2 || ld < d1 || !(c > 0.0f)) return hm_fail(nullptr, HM_E_ARG, "hm_rows_distance: bad arguments");
     if (b == 0) return HM_OK;
-    hipLaunchKernelGGL(hm_rows_distance_kernel, dim3((unsigned)std::min<int64_t>((b + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, x_dev, y_dev, b,
+    hipLaunchKernelGGL(hm_rows_distance_kernel, dim3((unsigned)std::min<int64_t>((b + 8 * HM_GATHER - 1) / (8 * HM_GATHER), 8192)), dim3(256), 0, (hipStream_t)stream, x_dev, y_dev, b,
                        ld, d1, sqrtf(c), sign_mode, out_dev);
     HM_HIP0(hipGetLastError());
     return HM_OK;

@@ -52,8 +52,28 @@ __device__ __forceinline__ float hm_wave_midpoint(int d, float w, float c, int s
     hm_wave_lds_sync();
     float r2 = 0.0f;
     if (project) {
-        // project (:41-56): sequential fmaf chain, every lane the same (LDS broadcast reads)
-        for (int k = 1; k <= d; ++k) r2 = __builtin_fmaf(ms.so[k], ms.so[k], r2);
+        // project (:41-56): the canonical order is a sequential fmaf chain over k = 1..d.  Each lane keeps its two
+        // elements in registers and the chain pulls them in order through the cross-lane network (eight requests in
+        // flight) -- a chain step costs a fused multiply-add, not an LDS round trip.
+        const float e0 = lane + 1 <= d ? ms.so[1 + lane] : 0.0f;          // k = 1 .. 64
+        const float e1 = lane + 65 <= d ? ms.so[65 + lane] : 0.0f;        // k = 65 .. 128
+        // (lanes past d hold 0, and fmaf(0, 0, r2) == r2: the chain may run to the next multiple of 8)
+#pragma unroll 1
+        for (int k0 = 0; k0 < d && k0 < 64; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = __shfl(e0, k0 + q, 64);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r2 = __builtin_fmaf(v[q], v[q], r2);
+        }
+#pragma unroll 1
+        for (int k0 = 64; k0 < d; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = __shfl(e1, k0 - 64 + q, 64);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r2 = __builtin_fmaf(v[q], v[q], r2);
+        }
         const float rr = __builtin_sqrtf(r2);
         const float x0 = __builtin_sqrtf(1.0f + (c * rr) * rr);
         hm_wave_lds_sync();

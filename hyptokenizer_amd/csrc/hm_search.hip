@@ -57,18 +57,18 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
     uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
     // a half-wave takes 32 consecutive entries per round (hm_halfwave_gather32): lane t finishes entry t
     const uint32_t hw = (blockIdx.x * HM_TAIL_THREADS + threadIdx.x) >> 5;          // half-wave id
-    const uint32_t stride = active * (HM_TAIL_THREADS >> 5) * 32u;
+    const uint32_t stride = active * (HM_TAIL_THREADS >> 5) * HM_GATHER;
     const int t32 = lane & 31;
-    for (uint32_t base = (hw & ~1u) * 32u; base < m; base += stride) {             // wave-uniform trip count
-        const uint32_t mybase = base + (hw & 1u) * 32u;
+    for (uint32_t base = (hw & ~1u) * HM_GATHER; base < m; base += stride) {             // wave-uniform trip count
+        const uint32_t mybase = base + (hw & 1u) * HM_GATHER;
         const uint32_t mine = mybase + t32;
         const uint4 en = a.ent[mine < m ? mine : m - 1];
-        const float u = hm_halfwave_gather32(lane, [&](int k) {
+        const float u = hm_halfwave_gather(lane, [&](int k) {
             const uint32_t ri = __shfl(en.y, (lane & 32) + k, 64), rj = __shfl(en.z, (lane & 32) + k, 64);
             return hm_img_u_halfwave(a.img, a.RS, a.d, ri, rj, a.sign_mode, lane);
         });
         const float dd = hm::dist_from_u(u, a.sqrt_c);
-        if (mine < m && dd < a.thr) {
+        if (t32 < HM_GATHER && mine < m && dd < a.thr) {
             const uint32_t db = hm::fbits(dd);
             if (hm_key_less(db, en.y, en.z, b0, b1, b2)) { b0 = db; b1 = en.y; b2 = en.z; }
         }
@@ -207,15 +207,15 @@ __device__ __forceinline__ void hm_rowpass_block(const float* __restrict__ img, 
     const int lane = threadIdx.x & 63, t = lane & 31;
     const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
     const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    for (int64_t base = (hw & ~(int64_t)1) * 32; base < n_partners; base += nhw * 32) {
-        const int64_t mybase = base + (hw & 1) * 32;
-        const float u = hm_halfwave_gather32(lane, [&](int k) {
+    for (int64_t base = (hw & ~(int64_t)1) * HM_GATHER; base < n_partners; base += nhw * HM_GATHER) {
+        const int64_t mybase = base + (hw & 1) * HM_GATHER;
+        const float u = hm_halfwave_gather(lane, [&](int k) {
             const int64_t r = mybase + k < n_partners ? mybase + k : n_partners - 1;
             return hm_img_u_halfwave(img, RS, d, row, r, sign_mode, lane);
         });
         const int64_t i = mybase + t;
         const float dd = hm::dist_from_u(u, sqrt_c);
-        if (i < n_partners && i != row && dd < thr) {
+        if (t < HM_GATHER && i < n_partners && i != row && dd < thr) {
             const uint32_t lo = (uint32_t)(i < row ? i : row), hi = (uint32_t)(i < row ? row : i);
             const uint32_t db = hm::fbits(dd);
             if (hm_key_less(db, lo, hi, b0, b1, b2)) { b0 = db; b1 = lo; b2 = hi; }
@@ -278,19 +278,19 @@ __global__ __launch_bounds__(256) void hm_post_distance_kernel(uint4* __restrict
     const int lane = threadIdx.x & 63;
     uint32_t nv = 0, nb = 0, bad = 0, nc = 0;
     const uint32_t hw = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    const uint32_t stride = ((gridDim.x * blockDim.x) >> 5) * 32u;
+    const uint32_t stride = ((gridDim.x * blockDim.x) >> 5) * HM_GATHER;
     const int t32 = lane & 31;
-    for (uint32_t base = (hw & ~1u) * 32u; base < m; base += stride) {
-        const uint32_t mybase = base + (hw & 1u) * 32u;
+    for (uint32_t base = (hw & ~1u) * HM_GATHER; base < m; base += stride) {
+        const uint32_t mybase = base + (hw & 1u) * HM_GATHER;
         const uint32_t mine = mybase + t32;
         const uint4 en = ent[mine < m ? mine : m - 1];
-        const float u = hm_halfwave_gather32(lane, [&](int k) {
+        const float u = hm_halfwave_gather(lane, [&](int k) {
             const uint32_t ri = __shfl(en.y, (lane & 32) + k, 64), rj = __shfl(en.z, (lane & 32) + k, 64);
             return hm_img_u_halfwave(img, RS, d, ri, rj, sign_mode, lane);
         });
         const float uc = hm::clamp_min_one(u);
         const float dd = hm::acosh_c(uc) / sqrt_c;
-        if (mine < m) {
+        if (t32 < HM_GATHER && mine < m) {
             const bool valid = dd < thr;
             nv += valid ? 1u : 0u;
             nb += (valid && en.w == 0u) ? 1u : 0u;

@@ -207,15 +207,18 @@ class MergeEngine:
         self._chk(self._L.hm_merge_append(self._h, int(i), int(j), float(w), float(c), _ptr(t), t.stride(0),
                                           int(new_row), self._stream()))
 
-    def merge_append_batch(self, I, J, W, c: float, table: torch.Tensor, first_row: int) -> None:
-        """Several merges in one launch: merge t -> row first_row + t (may read rows of earlier merges)."""
+    def merge_append_batch(self, I, J, W, c: float, table: torch.Tensor, first_row: int, independent: bool = False) -> None:
+        """Several merges in one launch: merge t -> row first_row + t.  ``independent``: no merge reads a row the
+        batch writes (all operands < first_row): all at once instead of a sequential chain."""
         t = self._check_table(table)
         ti, tj = self._idx(I), self._idx(J)
         tw = torch.as_tensor(np.ascontiguousarray(W, dtype=np.float32), device=self.device)
         if not (0 <= first_row and first_row + ti.numel() <= t.shape[0]):
             raise ValueError("merge batch outside the table")
+        if independent and ti.numel() and int(max(ti.max(), tj.max())) >= first_row:
+            raise ValueError("independent merge batch reads a row it writes")
         self._chk(self._L.hm_merge_append_batch(self._h, _ptr(ti), _ptr(tj), _ptr(tw), ti.numel(), float(c), _ptr(t),
-                                                t.stride(0), int(first_row), self._stream()))
+                                                t.stride(0), int(first_row), 1 if independent else 0, self._stream()))
 
     def truncate(self, n_rows: int) -> None:
         self._chk(self._L.hm_truncate(self._h, int(n_rows), self._stream()))

@@ -96,7 +96,7 @@ class AdaptiveMergeCache:
         self._arr = None                          # (d, i, j) arrays of not-yet-materialised entries
         self._pos = 0
         self._hit_count: Dict[Tuple[int, int], int] = {}
-        self._served: List[Tuple[np.ndarray, np.ndarray]] = []   # (i, j) arrays of batches served straight from the arrays
+        self._served: List[Tuple[np.ndarray, np.ndarray, int, int]] = []   # (i, j, lo, hi): batches served straight from the arrays
         self.miss_count: int = 0
         self._hits = 0                            # running sum(hit_count.values())
 
@@ -104,8 +104,8 @@ class AdaptiveMergeCache:
     @property
     def hit_count(self) -> Dict[Tuple[int, int], int]:
         """served pairs -> times served; batches popped as arrays are folded in when this is read"""
-        for ii, jj in self._served:
-            for key in zip(ii.tolist(), jj.tolist()):
+        for ii, jj, lo, hi in self._served:
+            for key in zip(ii[lo:hi].tolist(), jj[lo:hi].tolist()):
                 self._hit_count[key] = self._hit_count.get(key, 0) + 1
         self._served = []
         return self._hit_count
@@ -175,7 +175,7 @@ class AdaptiveMergeCache:
             self._pos = hi
             if hi >= len(d):
                 self._arr, self._pos = None, 0
-            self._served.append((i[lo:hi], j[lo:hi]))
+            self._served.append((i, j, lo, hi))
             self._hits += hi - lo
             return CandidateList(d[lo:hi], i[lo:hi], j[lo:hi], hi - lo)
         best = self._list[:n]
@@ -278,6 +278,50 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         self._refreshed = found
         return found
 
+    def _fast_forward(self, step: int, steps: int, log_every: int, adaptive_threshold: bool) -> int:
+        """Replays loop steps ``step, step + 1, ...`` while they are plain cache pops whose merges were issued ahead
+        of time (``_plan_merges``) and nothing is logged, sampled or rescaled in them (reference ``:511-576``: a cache
+        pop of 100, ``candidates[0]``, ``_merge_tokens``).  Returns the number of steps done (0: take the long way)."""
+        cache = self.cache
+        if cache._list or cache._arr is None or not self._plan:
+            return 0
+        d_arr, i_arr, j_arr = cache._arr
+        pos, n_arr = cache._pos, len(d_arr)
+        plan = self._plan
+        if pos >= n_arr or (int(i_arr[pos]), int(j_arr[pos]), self.current_vocab_size) != plan[-1]:
+            return 0
+        vocab, index, history, served = self.vocab, self.token2idx, self.merge_history, cache._served
+        done = hits = 0
+        s = step
+        while plan and pos < n_arr and s < steps:
+            if s % log_every == 0 or (s + 1) % log_every == 0 or (adaptive_threshold and s > 0 and s % 1000 == 0):
+                break
+            a, b, row = plan.pop()
+            hi = pos + 100 if pos + 100 < n_arr else n_arr
+            served.append((i_arr, j_arr, pos, hi))
+            hits += hi - pos
+            pos = hi
+            left = vocab[a]
+            right = vocab[b]
+            merged = left + right
+            vocab.append(merged)
+            index[merged] = row
+            history.append((left, right, merged))
+            done += 1
+            s += 1
+        if done:
+            cache._hits += hits
+            if pos >= n_arr:
+                cache._arr, cache._pos = None, 0
+            else:
+                cache._pos = pos
+            self.current_vocab_size += done
+            self.merges_since_rebuild += done
+            if self.merges_since_rebuild >= self.rebuild_frequency:
+                self.index_outdated = True
+            self._engine_key = self._table_key()
+        return done
+
     def _plan_merges(self, found: "CandidateList", steps_left: int) -> None:
         """Every merge up to the next refresh is known when a refresh returns (this
         step merges ``S[0]``, the following ones pop 100 cached entries each and merge the first of them,
@@ -305,7 +349,8 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         li = np.fromiter((len(vocab[a]) for a in ii.tolist()), np.float64, len(picks))
         lj = np.fromiter((len(vocab[b]) for b in jj.tolist()), np.float64, len(picks))
         w = lj / (li + lj)
-        eng.merge_append_batch(ii, jj, w.astype(np.float32), self.curvature, self.embeddings.data, n)
+        eng.merge_append_batch(ii, jj, w.astype(np.float32), self.curvature, self.embeddings.data, n,
+                               independent=bool(max(int(ii.max()), int(jj.max())) < n))
         self._plan = [(int(a), int(b), n + t) for t, (a, b) in enumerate(zip(ii.tolist(), jj.tolist()))][::-1]
 
     def _merge_tokens(self, i: int, j: int) -> None:
@@ -345,7 +390,7 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         consumption, empty-step handling, x1.1 every 1000 steps)."""
         from tqdm import tqdm
 
-        bar = tqdm(range(steps), desc="Optimizing merges", disable=TQDM_OFF)
+        bar = tqdm(total=steps, desc="Optimizing merges", disable=TQDM_OFF)
         empty_steps = 0
         stats = {"step": [], "vocab_size": [], "min_dist": [], "max_dist": [], "mean_dist": [], "num_candidates": []}
 
@@ -361,7 +406,18 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
                 self.merge_threshold = min(self.merge_threshold, ds["mean"] * 1.5)
                 logger.info(f"Adjusted initial merge threshold to {self.merge_threshold:.6f}")
 
-        for step in bar:
+        step = -1
+        while step + 1 < steps:
+            step += 1
+            if self._plan:
+                # the steps up to the next refresh / log line are fully determined: replay them without the per-step
+                # machinery (same pops, same merges, same bookkeeping)
+                done = self._fast_forward(step, steps, log_every, adaptive_threshold)
+                if done:
+                    if not bar.disable:
+                        bar.update(done)
+                    step += done - 1
+                    continue
             t0 = time.time()
             found = self._find_merge_candidates_fast()
             if self._refreshed is not None and found:
@@ -397,6 +453,7 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
             self._merge_tokens(best.token_i, best.token_j)
 
             if not bar.disable:                   # display only (tqdm formats the postfix even when disabled)
+                bar.update(1)
                 elapsed = time.time() - t0
                 cs = self.cache.get_stats()
                 bar.set_postfix({"vocab_size": self.current_vocab_size, "best_dist": best.distance,
@@ -407,4 +464,6 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
                             f"'{self.vocab[best.token_j]}' -> '{self.vocab[-1]}' (dist: {best.distance:.4f})")
             if adaptive_threshold and step > 0 and step % 1000 == 0:
                 self.merge_threshold *= 1.1
+        if not bar.disable:
+            bar.close()
         self.last_run_stats = stats     # the reference builds this dict and drops it (:484)

@@ -145,11 +145,12 @@ int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, float c, float*
                     int64_t new_row, void* stream);
 
 /* Several merges known in advance, one launch: merge t = midpoint of image rows (I[t], J[t]) with weight W[t] ->
- * row first_row + t of the table and of the image; a merge may read rows written by earlier merges of the batch.
+ * row first_row + t of the table and of the image.  independent = 0: a merge may read rows written by earlier merges
+ * of the batch (sequential chain); independent = 1: the caller guarantees every I[t], J[t] < first_row (all at once).
  * Replaces: the hyperbolic_merge.py:326-351 arithmetic of the ~100 merges a FastHyperbolicTokenizer performs
  * between two refreshes (fast_hyperbolic_merge.py:546-549), all of which are known when the refresh returns. */
 int hm_merge_append_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev, int64_t count,
-                          float c, float* X_dev, int64_t ld, int64_t first_row, void* stream);
+                          float c, float* X_dev, int64_t ld, int64_t first_row, int independent, void* stream);
 /* Forget image rows >= n_rows (undo rows appended ahead of time). */
 int hm_truncate(hm_engine* e, int64_t n_rows, void* stream);
 

@@ -49,6 +49,9 @@ class OracleEngine:
         if not thr > 0 or self._n < 2:
             e = np.empty(0, np.float32)
             return e, np.empty(0, np.int32), np.empty(0, np.int32), 0
+        if not count and k > 0:                      # the uncounted form: -1 when at least k candidates exist
+            d, i, j, total = O.pairwise_topk(self.X, self._n, float(c), thr, self.sign_mode, int(k), r0, r1, fast=self.fast)
+            return d, i, j, (-1 if total >= k else total)
         return O.pairwise_topk(self.X, self._n, float(c), thr, self.sign_mode, max(int(k), 1), r0, r1, fast=self.fast) \
             if k > 0 else (np.empty(0, np.float32), np.empty(0, np.int32), np.empty(0, np.int32),
                            O.pairwise_count(self.X, self._n, float(c), thr, self.sign_mode, r0, r1))
@@ -108,6 +111,21 @@ class OracleEngine:
     def rows_pair_distance(self, table, A, B, c):
         T = table.detach().cpu().numpy()
         return O.distance(T[np.asarray(A, np.int64)], T[np.asarray(B, np.int64)], float(c), self.sign_mode)
+
+    def merge_append_batch(self, I, J, W, c, table, first_row, independent=False):
+        for t, (i, j, w) in enumerate(zip(np.asarray(I).tolist(), np.asarray(J).tolist(), np.asarray(W).tolist())):
+            self.merge_append(int(i), int(j), np.float32(w), c, table, first_row + t)
+
+    def truncate(self, n_rows):
+        self.X[n_rows:] = 0
+        self._n = int(n_rows)
+
+    def count_candidates(self, c, thr, n_limit=-1):
+        n = self._n if n_limit < 0 else min(n_limit, self._n)
+        thr = float(np.float32(thr))
+        if not thr > 0 or n < 2:
+            return 0
+        return O.pairwise_count(self.X, n, float(c), thr, self.sign_mode, 0, n)
 
     # -- device-resident loops (same record format as MergeEngine) ---------------------------------
     def set_token_lengths(self, lengths):

@@ -356,6 +356,16 @@ def test_merge_batch_equals_sequential_merges(oracle, mode):
     assert a[3] == b[3] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(_bits(a[0]), _bits(b[0]))
     engA.truncate(n + 2)
     assert engA.n == n + 2
+    # independent form (every operand below first_row): all merges at once, same rows
+    engC, tabC = _engine(X, mode, n + 64)
+    engD, tabD = _engine(X, mode, n + 64)
+    I2 = np.array([3, 5, 7, 3, 800], np.int32)
+    J2 = np.array([9, 6, 899, 9, 2], np.int32)
+    W2 = np.array([0.5, 0.25, 0.75, 0.5, 0.3], np.float32)
+    engC.merge_append_batch(I2, J2, W2, 1.3, tabC, n, independent=True)
+    engD.merge_append_batch(I2, J2, W2, 1.3, tabD, n, independent=False)
+    assert np.array_equal(_bits(tabC.cpu().numpy()), _bits(tabD.cpu().numpy()))
+    assert engC.topk(1.3, thr, 20)[1].tolist() == engD.topk(1.3, thr, 20)[1].tolist()
 
 
 @pytest.mark.parametrize("mode", ["lorentz", "reference"])
