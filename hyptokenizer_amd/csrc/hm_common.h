@@ -73,6 +73,7 @@ struct ScanArgs {
     int shape;                    // host-side: block shape selector of the bf16 form (0: 256-row blocks, 1: 512-row blocks)
     int n;                        // live rows
     int row_begin, row_end;       // i range
+    int col_begin;                // only pairs with j >= col_begin (incremental refresh: the rows appended since the last one)
     int rb_first;                 // first row block
     int nct;                      // column tiles in total = ceil(n / cols per tile)
     // work decomposition: 1-D grid.  Blocks [0, n_items_a) take `ch_a` column tiles each of row
@@ -174,6 +175,13 @@ struct hm_engine {
     uint32_t last_cut_bits = 0;
     int64_t last_cut_k = 0;
     float last_cut_c = 0.f;
+    // the ordered list of the last whole-table top-k search (device copy): while rows are only appended, the next one is
+    // the k smallest of (that list) + (pairs with a new row)
+    uint4* d_prev = nullptr;
+    bool prev_valid = false;
+    bool incremental_topk = true;         // HM_TUNE_INCR_TOPK=0: every refresh scans the whole triangle
+    int64_t prev_k = 0, prev_n = 0;
+    float prev_thr = 0.f;
     bool debug_cut = false;               // hm_debug_force_cut: the next top-k starts from last_cut_bits as given
     // stats
     float last_scan_ms = 0.f;
@@ -208,7 +216,8 @@ Bounds hm_bounds(float thr, float c);
 
 // ---- hm_scan.hip ----
 bool hm_use_bf16(const hm_engine* e);
-bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t row_end, ScanArgs& a, dim3& grid, int64_t n_limit = -1);
+bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t row_end, ScanArgs& a, dim3& grid, int64_t n_limit = -1,
+                     int64_t col_begin = 0);
 hipError_t hm_launch_scan(hm_engine* e, int mode, const ScanArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0 = nullptr,
                           hipEvent_t ev1 = nullptr);
 int64_t hm_pairs_in_range(int64_t n, int64_t r0, int64_t r1);

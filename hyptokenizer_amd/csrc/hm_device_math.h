@@ -264,6 +264,23 @@ __device__ __forceinline__ float sinh_c(float x)
     return h * (t + t / (t + 1.0f));
 }
 
+// cosh_c(x) and sinh_c(x) for x >= 0 (or NaN) with the one expm1 both are built on evaluated once: the same
+// operations on the same values as the two functions above, so the same bits.
+__device__ __forceinline__ void cosh_sinh_c(float x, float& ch, float& sh)
+{
+    if (x != x || x < 0.0f) { ch = cosh_c(x); sh = sinh_c(x); return; }
+    const float t = expm1_c(x);
+    if (x < 0.34657359f) {
+        const float w = 1.0f + t;
+        ch = (x < 0.000244140625f) ? 1.0f : 1.0f + (t * t) / (w + w);
+    } else {
+        const float e = t + 1.0f;
+        ch = 0.5f * e + 0.5f / e;
+    }
+    if (x < 1.0f) sh = 0.5f * (2.0f * t - (t * t) / (t + 1.0f));
+    else sh = 0.5f * (t + t / (t + 1.0f));
+}
+
 // torch.clamp(u, min = 1 + 1e-8) in fp32 (the bound is exactly 1.0f); NaN propagates.
 __device__ __forceinline__ float clamp_min_one(float u)
 {

@@ -59,6 +59,7 @@ static int hm_engine_alloc(hm_engine* e)
     HM_HIP(hipMalloc(&e->ent, sizeof(uint4) * (size_t)e->ent_cap));
     HM_HIP(hipMalloc(&e->ent2, sizeof(uint4) * (size_t)e->ent_cap));
     HM_HIP(hipMalloc(&e->sorted, sizeof(uint4) * (size_t)e->sorted_cap));
+    HM_HIP(hipMalloc(&e->d_prev, sizeof(uint4) * (size_t)e->sorted_cap));
     HM_HIP(hipMalloc(&e->d_ctr, sizeof(uint32_t) * 8));
     HM_HIP(hipMemset(e->d_ctr, 0, sizeof(uint32_t) * 8));
     HM_HIP(hipMalloc(&e->d_rmax2, sizeof(uint32_t) * 2));
@@ -122,6 +123,7 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     if (const char* t = getenv("HM_TUNE_TAIL")) { const double v = atof(t); if (v >= 0.0 && v <= 0.9) e->tail_fraction = v; }
     if (const char* t = getenv("HM_TUNE_BIG_ROWS")) { const long v = atol(t); if (v >= 0) e->big_min_rows = v; }
     else if (const char* t2 = getenv("HM_TUNE_TM4_ROWS")) { const long v = atol(t2); if (v >= 0) e->big_min_rows = v; }   // round-1 name
+    if (const char* t = getenv("HM_TUNE_INCR_TOPK")) e->incremental_topk = atoi(t) != 0;
     if (const char* t = getenv("HM_TUNE_PERSIST")) { const int v = atoi(t); if (v >= 0 && v <= 9) e->persist = v; }
     if (const char* t = getenv("HM_TUNE_SHAPE")) { const int v = atoi(t); if (v >= 0 && v <= 3) e->force_shape = v; }
     if (const char* t = getenv("HM_TUNE_TAIL_DIV")) { const int v = atoi(t); if (v >= 1 && v <= 16) e->tail_div = v; }
@@ -148,7 +150,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
     void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts,
-                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len};
+                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev};
     for (void* q : dev_ptrs)
         if (q) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);

@@ -6,7 +6,7 @@
 
 // LDS scratch of one wave: the two operand rows, the scaled tangent and the result, in the reference's column
 // order (column 0 = time).
-struct MidScratch { float sx[HM_MAX_D1], sy[HM_MAX_D1], sv[HM_MAX_D1], so[HM_MAX_D1]; };
+struct MidScratch { float sx[HM_MAX_D1], sy[HM_MAX_D1], sv[HM_MAX_D1], so[HM_MAX_D1 + 12]; };
 
 __device__ __forceinline__ void hm_wave_lds_sync()
 {
@@ -47,30 +47,20 @@ __device__ __forceinline__ float hm_wave_midpoint(int d, float w, float c, int s
     float n2 = hm_halfwave_sum(d, lane, [&](int e) { return ms.sv[1 + e] * ms.sv[1 + e]; });
     if (n2 == n2 && n2 < 1.0e-8f) n2 = 1.0e-8f;
     const float nn = __builtin_sqrtf(n2);
-    const float ch = hm::cosh_c(nn), sh = hm::sinh_c(nn);
+    float ch, sh;
+    hm::cosh_sinh_c(nn, ch, sh);                               // cosh_c / sinh_c with their common expm1 evaluated once
     for (int k = lane; k <= d; k += 64) ms.so[k] = ch * ms.sx[k] + sh * (ms.sv[k] / nn);
+    if (lane < 8) ms.so[d + 1 + lane] = 0.0f;                  // zero tail: the chain below runs in steps of 8
     hm_wave_lds_sync();
     float r2 = 0.0f;
     if (project) {
-        // project (:41-56): the canonical order is a sequential fmaf chain over k = 1..d.  Each lane keeps its two
-        // elements in registers and the chain pulls them in order through the cross-lane network (eight requests in
-        // flight) -- a chain step costs a fused multiply-add, not an LDS round trip.
-        const float e0 = lane + 1 <= d ? ms.so[1 + lane] : 0.0f;          // k = 1 .. 64
-        const float e1 = lane + 65 <= d ? ms.so[65 + lane] : 0.0f;        // k = 65 .. 128
-        // (lanes past d hold 0, and fmaf(0, 0, r2) == r2: the chain may run to the next multiple of 8)
+        // project (:41-56): the canonical order is a sequential fmaf chain over k = 1..d; every lane runs it on LDS
+        // broadcast reads, eight operands fetched per step (fmaf(0, 0, r2) == r2: the zero tail does not change it)
 #pragma unroll 1
-        for (int k0 = 0; k0 < d && k0 < 64; k0 += 8) {
+        for (int k0 = 1; k0 <= d; k0 += 8) {
             float v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = __shfl(e0, k0 + q, 64);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) r2 = __builtin_fmaf(v[q], v[q], r2);
-        }
-#pragma unroll 1
-        for (int k0 = 64; k0 < d; k0 += 8) {
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = __shfl(e1, k0 - 64 + q, 64);
+            for (int q = 0; q < 8; ++q) v[q] = ms.so[k0 + q];
 #pragma unroll
             for (int q = 0; q < 8; ++q) r2 = __builtin_fmaf(v[q], v[q], r2);
         }

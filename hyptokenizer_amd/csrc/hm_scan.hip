@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             }
         }
         if (__ballot(ext_u < bound_f) == 0ull) return;
-        const bool full = rows_full && (j0s > i0w + WAVE_ROWS - 1) && (j0s + 31 < p.n);
+        const bool full = rows_full && (j0s > i0w + WAVE_ROWS - 1) && (j0s + 31 < p.n) && (j0s >= p.col_begin);
         unsigned long long wkey = ~0ull;
         bool wrote = false;
 #pragma unroll 1
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
                 const float u = SIGN ? -wv : wv;
                 const int i = ib + (e & 3) + 8 * (e >> 2);
                 bool pass = u < bnd;
-                if (!full) pass = pass && (i < j) && (j < p.n) && (i >= p.row_begin) && (i < p.row_end);
+                if (!full) pass = pass && (i < j) && (j < p.n) && (j >= p.col_begin) && (i >= p.row_begin) && (i < p.row_end);
                 if (!pass) return;
                 const float up = u < 1.0f ? 1.0f : u;
                 const uint32_t ub = hm::fbits(up);
@@ -419,6 +419,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         ct1 = ct0 + p.ch_b;
     }
     if (ct0 < (rb * BLOCK_ROWS) / COLS) ct0 = (rb * BLOCK_ROWS) / COLS;   // left of the diagonal: no i < j
+    if (ct0 < p.col_begin / COLS) ct0 = p.col_begin / COLS;               // partner rows in front of col_begin are not asked for
     if (ct1 > p.nct) ct1 = p.nct;
     if (ct0 >= ct1) { if (p.persist) continue; else break; }
 
@@ -579,7 +580,7 @@ static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, h
     // timed launches carry their events in the dispatch itself (start / stop timestamps of this kernel): a pair of
     // hipEventRecord calls around it costs two ~6 us bubbles on the stream
     ScanArgs b = a;
-    if (MODE != HM_MODE_HIST && e->persist) {
+    if (MODE != HM_MODE_HIST && e->persist && a.col_begin == 0) {
         // resident grid, equal shares of the tile sequence (see the kernel's work loop)
         constexpr int block_rows = 32 * TM * WPB, cols = 32 * SUB, tpr = block_rows / cols;
         const long long nrb = (a.row_end - 1) / block_rows - a.rb_first + 1;
@@ -685,7 +686,8 @@ hipError_t hm_launch_scan(hm_engine* e, int mode, const ScanArgs& a, dim3 grid, 
 }
 
 // common argument preparation; returns false when the row range is empty
-bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t row_end, ScanArgs& a, dim3& grid, int64_t n_limit)
+bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t row_end, ScanArgs& a, dim3& grid, int64_t n_limit,
+                     int64_t col_begin)
 {
     // n_limit: search among the first n_limit rows only (rows are only ever appended: the pairs of an earlier table)
     const int64_t n = (n_limit >= 0 && n_limit < e->n) ? n_limit : e->n;
@@ -735,7 +737,9 @@ bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t r
     while (ch > 4 && (int64_t)nrb * ((a.nct + ch - 1) / ch) < 1024) ch >>= 1;
     // phase B = the last ~tail_fraction of the work (row blocks near the bottom of the triangle), cut into
     // chunks a quarter the size
-    a.ctmin_a = (int)((int64_t)a.rb_first * block_rows / cols);
+    a.col_begin = (int)std::max<int64_t>(col_begin, 0);
+    const int ct_lo = a.col_begin / cols;
+    a.ctmin_a = std::max((int)((int64_t)a.rb_first * block_rows / cols), ct_lo);
     int rb_split = rb_last + 1;
     int ch_b = ch;
     if (ch >= 8 && nrb >= 16) {
@@ -751,7 +755,7 @@ bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t r
     a.chunks_a = std::max(1, (a.nct - a.ctmin_a + ch - 1) / ch);
     a.rb_split = rb_split;
     a.ch_b = ch_b;
-    a.ctmin_b = (int)((int64_t)rb_split * block_rows / cols);
+    a.ctmin_b = std::max((int)((int64_t)rb_split * block_rows / cols), ct_lo);
     a.chunks_b = std::max(1, (a.nct - a.ctmin_b + ch_b - 1) / ch_b);
     a.n_items_a = (rb_split - a.rb_first) * a.chunks_a;
     const int n_items_b = (rb_last + 1 - rb_split) * a.chunks_b;

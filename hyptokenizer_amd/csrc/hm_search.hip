@@ -763,6 +763,45 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
     return HM_OK;
 }
 
+// Incremental refresh (rows are only ever appended).  The ordered list S[:k] of the previous
+// whole-table search is still the k smallest of the pairs among the rows it saw; the k smallest of the grown table
+// are therefore the k smallest of S[:k] + the pairs that involve a NEW row (j >= prev_n).  Only the last column
+// tile(s) are scanned (cut = largest u' of S[:k], so every new pair that could enter is emitted) and the two lists
+// are merged by the exact selection.  Preconditions checked by the caller; the exact total is not produced here.
+static int hm_topk_incremental(hm_engine* e, float c, float thr, int64_t k, hipStream_t s, uint32_t* kk_out)
+{
+    *kk_out = 0;
+    hm_flush_pending_timing(e);
+    e->last_scan_ms = 0.f; e->last_pairs = 0; e->last_emitted = 0; e->last_passes = 0;
+    const Bounds b = hm_bounds(thr, c);
+    uint32_t m_new = 0;
+    if (e->n > e->prev_n) {
+        ScanArgs a; dim3 grid;
+        if (!hm_prepare_scan(e, b, 0, -1, a, grid, -1, e->prev_n)) return hm_fail(e, HM_E_STATE, "incremental refresh: empty scan");
+        a.count_sure = 0;
+        a.cut_bits = e->last_cut_bits + HM_TIE_SLACK;
+        a.tie_imax = 0x7fffffff;
+        HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
+        HM_HIP(hipMemsetAsync(e->d_ctr64, 0, sizeof(unsigned long long) * 4, s));
+        HM_HIP(hm_launch_scan(e, HM_MODE_TOPK, a, grid, s));
+        hipLaunchKernelGGL(hm_post_distance_kernel, dim3(256), dim3(256), 0, s, e->ent, e->d_ctr64, e->ent_cap, e->img, e->RS, e->d,
+                           e->sign_mode, sqrtf(c), thr, a.cut_bits, a.tie_imax, e->d_ctr + 1);
+        HM_HIP(hipGetLastError());
+        HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_ctr64, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipStreamSynchronize(s));
+        e->last_passes = 1;
+        e->last_emitted = (int64_t)e->h->ctr64[2];
+        if (e->h->ctr64[2] + (uint64_t)k > (uint64_t)e->ent_cap) return HM_E_CAPACITY;     // (caller falls back to the full search)
+        m_new = (uint32_t)e->h->ctr64[2];
+    }
+    // union: the new entries (already in e->ent, invalid ones carry all-ones keys) + the previous list
+    HM_HIP(hipMemcpyAsync(e->ent + m_new, e->d_prev, sizeof(uint4) * (size_t)k, hipMemcpyDeviceToDevice, s));
+    const int rc = hm_select_sorted(e, e->ent, e->ent2, m_new + (uint32_t)k, (uint32_t)k, s);
+    if (rc) return rc;
+    *kk_out = (uint32_t)k;
+    return HM_OK;
+}
+
 // common body of hm_pairwise_topk / hm_pairwise_topk_nocount
 static int hm_topk_impl(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, bool want_count,
                         float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count, void* stream)
@@ -776,17 +815,30 @@ static int hm_topk_impl(hm_engine* e, float c, float thr, int64_t k, int64_t row
     hipStream_t s = (hipStream_t)stream;
     HM_HIP(hipSetDevice(e->device));
     *n_out = 0; *count = 0;
-    int64_t valid = 0, total = 0;
-    uint4* res = nullptr;
-    int rc = hm_topk_core(e, c, thr, k, row_begin, row_end, false, want_count || k == 0, -1, &valid, &total, &res, s);
-    if (rc) return rc;
-    *count = total;
-    const uint32_t kk = (uint32_t)std::min<int64_t>(k, valid);
-    if (kk == 0 || !res) return HM_OK;
-    const uint32_t m = (uint32_t)std::min<uint64_t>(e->h->ctr64[2], e->ent_cap);
-    rc = hm_select_sorted(e, res, e->ent2, m, kk, s);
-    if (rc) return rc;
+    const bool whole = row_begin <= 0 && (row_end < 0 || row_end >= e->n - 1);
+    uint32_t kk = 0;
+    bool done = false;
+    if (!want_count && k > 0 && whole && e->incremental_topk && e->have_cut && e->prev_valid && e->prev_k == k && e->last_cut_c == c &&
+        thr >= e->prev_thr && e->n >= e->prev_n && e->n - e->prev_n <= 8192 && e->last_cut_bits > 0x3f800000u && !e->debug_cut) {
+        const int rc = hm_topk_incremental(e, c, thr, k, s, &kk);
+        if (rc == HM_OK) { done = true; *count = -1; }
+        else if (rc != HM_E_CAPACITY) return rc;
+    }
+    if (!done) {
+        int64_t valid = 0, total = 0;
+        uint4* res = nullptr;
+        int rc = hm_topk_core(e, c, thr, k, row_begin, row_end, false, want_count || k == 0, -1, &valid, &total, &res, s);
+        if (rc) return rc;
+        *count = total;
+        kk = (uint32_t)std::min<int64_t>(k, valid);
+        if (kk == 0 || !res) { e->prev_valid = false; return HM_OK; }
+        const uint32_t m = (uint32_t)std::min<uint64_t>(e->h->ctr64[2], e->ent_cap);
+        rc = hm_select_sorted(e, res, e->ent2, m, kk, s);
+        if (rc) return rc;
+    }
     HM_HIP(hipMemcpyAsync(e->h_sorted, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToHost, s));
+    const bool keep = (kk == k && whole);
+    if (keep) HM_HIP(hipMemcpyAsync(e->d_prev, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToDevice, s));
     HM_HIP(hipStreamSynchronize(s));
     uint32_t mx = 0;
     for (uint32_t t = 0; t < kk; ++t) {
@@ -797,13 +849,18 @@ static int hm_topk_impl(hm_engine* e, float c, float thr, int64_t k, int64_t row
     *n_out = kk;
     // remember the largest u' of the selection: while rows are only appended, the k-th smallest key can
     // only move down, so this cut (+ tie slack) is a guaranteed superset for the next refresh
-    if (kk == k && row_begin <= 0 && (row_end < 0 || row_end >= e->n - 1)) {
+    if (keep) {
         e->have_cut = true;
         e->last_cut_bits = mx;
         e->last_cut_k = k;
         e->last_cut_c = c;
+        e->prev_valid = true;
+        e->prev_k = k;
+        e->prev_n = e->n;
+        e->prev_thr = thr;
     } else {
         e->have_cut = false;
+        e->prev_valid = false;
     }
     return HM_OK;
 }
