@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "hm_rows_minkowski", "hm_rows_distance", "hm_rows_log_map", "hm_rows_exp_map", "hm_rows_project",
     "hm_last_scan_stats", "hm_scan_totals", "hm_set_prefilter", "hm_pairwise_topk_nocount", "hm_pairwise_count",
     "hm_merge_append_batch", "hm_truncate", "hm_set_token_lengths", "hm_std_merge_steps", "hm_incr_merge_steps",
-    "hm_coherence_batch", "hm_project_table", "hm_debug_force_cut", "hm_randperm_prefix",
+    "hm_coherence_batch", "hm_project_table", "hm_debug_force_cut", "hm_randperm_prefix", "hm_merge_append_batch_host",
 )
 
 
@@ -76,6 +76,7 @@ def load() -> C.CDLL:
     L.hm_pairwise_topk_nocount.argtypes = [vp, f32, f32, i64, i64, i64, vp, vp, vp, pi64, pi64, vp]
     L.hm_pairwise_count.argtypes = [vp, f32, f32, i64, pi64, vp]
     L.hm_merge_append_batch.argtypes = [vp, vp, vp, vp, i64, f32, vp, i64, i64, C.c_int, vp]
+    L.hm_merge_append_batch_host.argtypes = [vp, vp, vp, vp, i64, f32, vp, i64, i64, C.c_int, vp]
     L.hm_truncate.argtypes = [vp, i64, vp]
     L.hm_set_token_lengths.argtypes = [vp, vp, i64, vp]
     L.hm_std_merge_steps.argtypes = [vp, f32, f32, vp, i64, i64, vp, pi64, vp]

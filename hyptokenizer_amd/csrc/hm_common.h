@@ -53,7 +53,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_TAIL_SOLO 1024u
 #define HM_ROWPASS_BLOCKS 256      // blocks of the one-row-vs-all reduction
 #define HM_PART_SLOTS 256          // partial records (>= HM_TAIL_BLOCKS, HM_ROWPASS_BLOCKS)
-#define HM_LOOP_MAX_STEPS 64       // steps one device-resident loop call may enqueue
+#define HM_LOOP_MAX_STEPS 64
+#define HM_BATCH_MAX 4096          // merges per hm_merge_append_batch_host call       // steps one device-resident loop call may enqueue
 
 // prefilter forms (hm_engine_create / hm_set_prefilter)
 #define HM_PREFILTER_AUTO 0
@@ -178,6 +179,11 @@ struct hm_engine {
     // the ordered list of the last whole-table top-k search (device copy): while rows are only appended, the next one is
     // the k smallest of (that list) + (pairs with a new row)
     uint4* d_prev = nullptr;
+    // staging of host-side merge batches (hm_merge_append_batch_host): pinned + device, HM_BATCH_MAX entries x {i, j, w}
+    int32_t* h_batch = nullptr;
+    int32_t* d_batch = nullptr;
+    hipEvent_t ev_batch = nullptr;
+    bool batch_in_flight = false;
     bool prev_valid = false;
     bool incremental_topk = true;         // HM_TUNE_INCR_TOPK=0: every refresh scans the whole triangle
     int64_t prev_k = 0, prev_n = 0;

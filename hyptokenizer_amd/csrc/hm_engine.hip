@@ -60,6 +60,9 @@ static int hm_engine_alloc(hm_engine* e)
     HM_HIP(hipMalloc(&e->ent2, sizeof(uint4) * (size_t)e->ent_cap));
     HM_HIP(hipMalloc(&e->sorted, sizeof(uint4) * (size_t)e->sorted_cap));
     HM_HIP(hipMalloc(&e->d_prev, sizeof(uint4) * (size_t)e->sorted_cap));
+    HM_HIP(hipMalloc(&e->d_batch, sizeof(int32_t) * 3 * HM_BATCH_MAX));
+    HM_HIP(hipHostMalloc(&e->h_batch, sizeof(int32_t) * 3 * HM_BATCH_MAX, hipHostMallocDefault));
+    HM_HIP(hipEventCreateWithFlags(&e->ev_batch, hipEventDisableTiming));
     HM_HIP(hipMalloc(&e->d_ctr, sizeof(uint32_t) * 8));
     HM_HIP(hipMemset(e->d_ctr, 0, sizeof(uint32_t) * 8));
     HM_HIP(hipMalloc(&e->d_rmax2, sizeof(uint32_t) * 2));
@@ -150,11 +153,13 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
     void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts,
-                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev};
+                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch};
     for (void* q : dev_ptrs)
         if (q) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);
     if (e->h_sorted) (void)hipHostFree(e->h_sorted);
+    if (e->h_batch) (void)hipHostFree(e->h_batch);
+    if (e->ev_batch) (void)hipEventDestroy(e->ev_batch);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     delete e;

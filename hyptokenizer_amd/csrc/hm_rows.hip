@@ -478,6 +478,36 @@ extern "C" int hm_merge_append_batch(hm_engine* e, const int32_t* I_dev, const i
     return HM_OK;
 }
 
+// the same with the batch in HOST memory (the fast tokenizer's plan): one pinned staging copy + one launch
+extern "C" int hm_merge_append_batch_host(hm_engine* e, const int32_t* I_host, const int32_t* J_host, const float* W_host, int64_t count,
+                                          float c, float* X_dev, int64_t ld, int64_t first_row, int independent, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_merge_append_batch_host: engine is NULL");
+    if (count < 0 || count > HM_BATCH_MAX || (count > 0 && (!I_host || !J_host || !W_host)))
+        return hm_fail(e, HM_E_ARG, "hm_merge_append_batch_host: bad arguments (at most 4096 merges per call)");
+    if (count == 0) return HM_OK;
+    for (int64_t t = 0; t < count; ++t) {
+        const int64_t lim = independent ? first_row : first_row + t;      // what the merge may read
+        if (I_host[t] < 0 || J_host[t] < 0 || I_host[t] >= lim || J_host[t] >= lim || lim > e->max_rows)
+            return hm_fail(e, HM_E_ARG, "hm_merge_append_batch_host: a merge reads a row that does not exist yet");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    if (e->batch_in_flight) { HM_HIP(hipEventSynchronize(e->ev_batch)); e->batch_in_flight = false; }   // staging buffer free again
+    memcpy(e->h_batch, I_host, sizeof(int32_t) * (size_t)count);
+    memcpy(e->h_batch + HM_BATCH_MAX, J_host, sizeof(int32_t) * (size_t)count);
+    memcpy(e->h_batch + 2 * HM_BATCH_MAX, W_host, sizeof(float) * (size_t)count);
+    HM_HIP(hipMemcpyAsync(e->d_batch, e->h_batch, sizeof(int32_t) * 3 * HM_BATCH_MAX, hipMemcpyHostToDevice, s));
+    HM_HIP(hipEventRecord(e->ev_batch, s));
+    e->batch_in_flight = true;
+    // (row-existence of the operands was checked above against first_row; hm_merge_append_batch checks the rest)
+    const int64_t n_keep = e->n;
+    if (first_row > e->n) return hm_fail(e, HM_E_ARG, "hm_merge_append_batch_host: first_row beyond the live rows");
+    (void)n_keep;
+    return hm_merge_append_batch(e, e->d_batch, e->d_batch + HM_BATCH_MAX, reinterpret_cast<const float*>(e->d_batch + 2 * HM_BATCH_MAX),
+                                 count, c, X_dev, ld, first_row, independent, stream);
+}
+
 extern "C" int hm_coherence_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev, const int32_t* S_dev,
                                   int64_t b, int ns, float c, float* out_dev, void* stream)
 {

@@ -209,16 +209,19 @@ class MergeEngine:
 
     def merge_append_batch(self, I, J, W, c: float, table: torch.Tensor, first_row: int, independent: bool = False) -> None:
         """Several merges in one launch: merge t -> row first_row + t.  ``independent``: no merge reads a row the
-        batch writes (all operands < first_row): all at once instead of a sequential chain."""
+        batch writes (all operands < first_row): all at once instead of a sequential chain.  Host arrays (numpy /
+        lists, at most 4096 merges per call) go through the engine's pinned staging buffer."""
         t = self._check_table(table)
-        ti, tj = self._idx(I), self._idx(J)
-        tw = torch.as_tensor(np.ascontiguousarray(W, dtype=np.float32), device=self.device)
-        if not (0 <= first_row and first_row + ti.numel() <= t.shape[0]):
+        ii = np.ascontiguousarray(I, dtype=np.int32)
+        jj = np.ascontiguousarray(J, dtype=np.int32)
+        ww = np.ascontiguousarray(W, dtype=np.float32)
+        if not (0 <= first_row and first_row + ii.shape[0] <= t.shape[0]):
             raise ValueError("merge batch outside the table")
-        if independent and ti.numel() and int(max(ti.max(), tj.max())) >= first_row:
-            raise ValueError("independent merge batch reads a row it writes")
-        self._chk(self._L.hm_merge_append_batch(self._h, _ptr(ti), _ptr(tj), _ptr(tw), ti.numel(), float(c), _ptr(t),
-                                                t.stride(0), int(first_row), 1 if independent else 0, self._stream()))
+        for lo in range(0, ii.shape[0], 4096):
+            hi = min(lo + 4096, ii.shape[0])
+            self._chk(self._L.hm_merge_append_batch_host(self._h, _np_ptr(ii[lo:hi]), _np_ptr(jj[lo:hi]), _np_ptr(ww[lo:hi]), hi - lo,
+                                                         float(c), _ptr(t), t.stride(0), int(first_row) + lo,
+                                                         1 if independent else 0, self._stream()))
 
     def truncate(self, n_rows: int) -> None:
         self._chk(self._L.hm_truncate(self._h, int(n_rows), self._stream()))

@@ -281,46 +281,60 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
     def _fast_forward(self, step: int, steps: int, log_every: int, adaptive_threshold: bool) -> int:
         """Replays loop steps ``step, step + 1, ...`` while they are plain cache pops whose merges were issued ahead
         of time (``_plan_merges``) and nothing is logged, sampled or rescaled in them (reference ``:511-576``: a cache
-        pop of 100, ``candidates[0]``, ``_merge_tokens``).  Returns the number of steps done (0: take the long way)."""
-        cache = self.cache
-        if cache._list or cache._arr is None or not self._plan:
+        pop of 100, ``candidates[0]``, ``_merge_tokens``) -- all of them at once, with list operations instead of a
+        Python statement per step.  Returns the number of steps done (0: take the long way)."""
+        cache, plan = self.cache, self._plan
+        if plan is None or cache._list or cache._arr is None:
             return 0
         d_arr, i_arr, j_arr = cache._arr
-        pos, n_arr = cache._pos, len(d_arr)
-        plan = self._plan
-        if pos >= n_arr or (int(i_arr[pos]), int(j_arr[pos]), self.current_vocab_size) != plan[-1]:
+        pos, n_arr, p = cache._pos, len(d_arr), plan.pos
+        n = self.current_vocab_size
+        if pos >= n_arr or not plan.matches(int(i_arr[pos]), int(j_arr[pos]), n):
             return 0
-        vocab, index, history, served = self.vocab, self.token2idx, self.merge_history, cache._served
-        done = hits = 0
-        s = step
-        while plan and pos < n_arr and s < steps:
-            if s % log_every == 0 or (s + 1) % log_every == 0 or (adaptive_threshold and s > 0 and s % 1000 == 0):
-                break
-            a, b, row = plan.pop()
-            hi = pos + 100 if pos + 100 < n_arr else n_arr
-            served.append((i_arr, j_arr, pos, hi))
-            hits += hi - pos
-            pos = hi
-            left = vocab[a]
-            right = vocab[b]
-            merged = left + right
-            vocab.append(merged)
-            index[merged] = row
-            history.append((left, right, merged))
-            done += 1
-            s += 1
-        if done:
-            cache._hits += hits
-            if pos >= n_arr:
-                cache._arr, cache._pos = None, 0
-            else:
-                cache._pos = pos
-            self.current_vocab_size += done
-            self.merges_since_rebuild += done
-            if self.merges_since_rebuild >= self.rebuild_frequency:
-                self.index_outdated = True
-            self._engine_key = self._table_key()
-        return done
+        # how many steps until something other than pop + merge happens
+        k = min(len(plan.i) - p, (n_arr - pos + 99) // 100, steps - step)
+        if step % log_every == 0:
+            return 0
+        k = min(k, log_every - 1 - step % log_every)            # step s with (s + 1) % log_every == 0 logs a line
+        if adaptive_threshold:
+            k = min(k, 1000 - step % 1000 if step % 1000 else 0)  # step s > 0 with s % 1000 == 0 rescales the threshold
+        if k <= 0:
+            return 0
+        A, B = plan.i[p:p + k], plan.j[p:p + k]
+        vocab = self.vocab
+        lefts = [vocab[a] for a in A]
+        rights = [vocab[b] for b in B]
+        merged = [x + y for x, y in zip(lefts, rights)]
+        vocab.extend(merged)
+        self.token2idx.update(zip(merged, range(n, n + k)))
+        self.merge_history.extend(zip(lefts, rights, merged))
+        hi = min(pos + 100 * k, n_arr)
+        cache._served.append((i_arr, j_arr, pos, hi))
+        cache._hits += hi - pos
+        if hi >= n_arr:
+            cache._arr, cache._pos = None, 0
+        else:
+            cache._pos = hi
+        plan.pos = p + k
+        if plan.pos >= len(plan.i):
+            self._plan = None
+        self.current_vocab_size = n + k
+        self.merges_since_rebuild += k
+        if self.merges_since_rebuild >= self.rebuild_frequency:
+            self.index_outdated = True
+        self._engine_key = self._table_key()
+        return k
+
+    def _token_lengths(self) -> np.ndarray:
+        """len(vocab[r]) for every row, kept as an array and extended as tokens are appended"""
+        lens = getattr(self, "_lens", None)
+        n = len(self.vocab)
+        if lens is None or len(lens) > n:
+            lens = np.fromiter(map(len, self.vocab), np.int64, n)
+        elif len(lens) < n:
+            lens = np.concatenate([lens, np.fromiter(map(len, self.vocab[len(lens):]), np.int64, n - len(lens))])
+        self._lens = lens
+        return lens
 
     def _plan_merges(self, found: "CandidateList", steps_left: int) -> None:
         """Every merge up to the next refresh is known when a refresh returns (this
@@ -329,7 +343,7 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         engine as ONE launch; the loop's ``_merge_tokens`` calls then find their rows already written and
         only do the string bookkeeping.  Capped by the steps the loop has left and by the table size."""
         cls = type(self)
-        if (not self.batch_merges or self.shard is not None or self._plan
+        if (not self.batch_merges or self.shard is not None or self._plan is not None
                 or cls._find_merge_candidates_fast is not FastHyperbolicTokenizer._find_merge_candidates_fast
                 or cls._merge_tokens is not FastHyperbolicTokenizer._merge_tokens
                 or {"_merge_tokens", "_find_merge_candidates_fast", "_append_token"} & set(self.__dict__)):
@@ -339,19 +353,20 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         if stored == 0 or not hasattr(eng, "merge_append_batch"):
             return
         n = self.current_vocab_size
-        picks = [0] + list(range(0, stored, 100))
-        picks = picks[: max(0, min(steps_left, self.max_vocab_size - n))]
-        if len(picks) < 2:
+        count = min(1 + (stored + 99) // 100, steps_left, self.max_vocab_size - n)
+        if count < 2:
             return
-        ii = found._i[picks].astype(np.int32)
-        jj = found._j[picks].astype(np.int32)
-        vocab = self.vocab
-        li = np.fromiter((len(vocab[a]) for a in ii.tolist()), np.float64, len(picks))
-        lj = np.fromiter((len(vocab[b]) for b in jj.tolist()), np.float64, len(picks))
+        picks = np.arange(-100, 100 * (count - 1), 100)
+        picks[0] = 0                                              # [0, 0, 100, 200, ...]
+        ii = found._i[picks]
+        jj = found._j[picks]
+        lens = self._token_lengths()
+        li, lj = lens[ii], lens[jj]
         w = lj / (li + lj)
         eng.merge_append_batch(ii, jj, w.astype(np.float32), self.curvature, self.embeddings.data, n,
                                independent=bool(max(int(ii.max()), int(jj.max())) < n))
-        self._plan = [(int(a), int(b), n + t) for t, (a, b) in enumerate(zip(ii.tolist(), jj.tolist()))][::-1]
+        from .hyperbolic_merge import _MergePlan
+        self._plan = _MergePlan(ii.tolist(), jj.tolist(), n)
 
     def _merge_tokens(self, i: int, j: int) -> None:
         super()._merge_tokens(i, j)

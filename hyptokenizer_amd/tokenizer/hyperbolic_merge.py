@@ -67,6 +67,18 @@ def threshold_for_double_compare(thr: float) -> float:
     return float(t)
 
 
+class _MergePlan:
+    """Merges issued to the engine ahead of the host loop: merge t = (i[t], j[t]) -> row row0 + t; `pos` = next one."""
+    __slots__ = ("i", "j", "row0", "pos")
+
+    def __init__(self, i, j, row0):
+        self.i, self.j, self.row0, self.pos = i, j, row0, 0
+
+    def matches(self, i: int, j: int, row: int) -> bool:
+        p = self.pos
+        return p < len(self.i) and self.i[p] == i and self.j[p] == j and self.row0 + p == row
+
+
 class HyperbolicTokenizer:
     """Tokenizer whose merges are chosen by hyperbolic distance between token embeddings."""
 
@@ -120,7 +132,7 @@ class HyperbolicTokenizer:
         self.prefilter = prefilter
         self._inc = None              # incremental search state: ((threshold, curvature), rows covered, best (d, i, j) | None)
         self._len_state = None        # (engine id, rows) whose token lengths the engine holds (device-resident loops)
-        self._plan = []               # merges already issued to the engine ahead of the host loop: (i, j, row), next first
+        self._plan = None             # _MergePlan: merges already issued to the engine ahead of the host loop
         self.device_loop = True       # optimize_merges may run its steps in batches on the device
 
     # ------------------------------------------------------------------------------------------
@@ -235,9 +247,12 @@ class HyperbolicTokenizer:
         n = self.current_vocab_size
         if n >= self.max_vocab_size:
             raise ValueError(f"Maximum vocabulary size {self.max_vocab_size} reached. Cannot merge more tokens.")
-        if self._plan:
-            if self._plan[-1] == (i, j, n):       # issued ahead of time (a batch of merges known in advance): row n is there
-                self._plan.pop()
+        plan = self._plan
+        if plan is not None:
+            if plan.matches(i, j, n):             # issued ahead of time (a batch of merges known in advance): row n is there
+                plan.pos += 1
+                if plan.pos >= len(plan.i):
+                    self._plan = None
                 self._append_token(i, j)
                 self._engine_key = self._table_key()
                 return
@@ -249,8 +264,8 @@ class HyperbolicTokenizer:
 
     def _cancel_plan(self) -> None:
         """The loop left the path a batch of merges was issued for: drop the rows appended ahead of time."""
-        if self._plan:
-            self._plan = []
+        if self._plan is not None:
+            self._plan = None
             n = self.current_vocab_size
             self._engine.truncate(n)
             self.embeddings.data[n:].zero_()

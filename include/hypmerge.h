@@ -151,6 +151,9 @@ int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, float c, float*
  * between two refreshes (fast_hyperbolic_merge.py:546-549), all of which are known when the refresh returns. */
 int hm_merge_append_batch(hm_engine* e, const int32_t* I_dev, const int32_t* J_dev, const float* W_dev, int64_t count,
                           float c, float* X_dev, int64_t ld, int64_t first_row, int independent, void* stream);
+/* The same with I / J / W in HOST memory (at most 4096 merges): staged through the engine's pinned buffer. */
+int hm_merge_append_batch_host(hm_engine* e, const int32_t* I_host, const int32_t* J_host, const float* W_host, int64_t count,
+                               float c, float* X_dev, int64_t ld, int64_t first_row, int independent, void* stream);
 /* Forget image rows >= n_rows (undo rows appended ahead of time). */
 int hm_truncate(hm_engine* e, int64_t n_rows, void* stream);
 
