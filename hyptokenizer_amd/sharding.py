@@ -63,6 +63,14 @@ class ShardContext:
         self._host = torch.zeros(4 * self.world, dtype=torch.int32)
         if self.device.type == "cuda":
             self._host = self._host.pin_memory()
+        self._rec_dev = {}          # engine device -> int32[4] record the engine writes (always device memory)
+
+    def record_buffer(self, device: torch.device) -> torch.Tensor:
+        """The 16-byte record an engine on `device` writes with ``argmin_into`` (allocated once per device)."""
+        key = str(device)
+        if key not in self._rec_dev:
+            self._rec_dev[key] = torch.zeros(4, dtype=torch.int32, device=device)
+        return self._rec_dev[key]
 
     def row_range(self, n: int) -> Tuple[int, int]:
         b = partition_rows(n, self.world)
@@ -122,15 +130,23 @@ class ShardContext:
 
 
 def sharded_argmin(engine, ctx: ShardContext, c: float, thr: float):
-    """Global nearest pair.  With an engine that can leave its record on the device
-    (``argmin_into``) the step costs one host synchronisation: scan -> record in HBM -> all-gather
-    over RCCL on the same stream -> one 16*world-byte read-back."""
+    """Global nearest pair.  An engine that can leave its record on the device (``argmin_into``) always does: the
+    search is asynchronous, armed for the next one of the same range, and costs ONE host synchronisation per step --
+    scan -> record in HBM -> all-gather on the same stream -> one 16*world-byte read-back (RCCL, backend "nccl"), or
+    record -> host -> all-gather over the CPU backend (gloo: tests, ranks that share a GPU).  The same engine code
+    path (armed / seeded searches, overflow reports, row ranges that move as the table grows) either way."""
     r0, r1 = ctx.row_range(engine.n)
-    if hasattr(engine, "argmin_into") and ctx.device.type == "cuda":
-        engine.argmin_into(c, thr, r0, r1, ctx._rec)
-        dist.all_gather_into_tensor(ctx._recs, ctx._rec, group=ctx.group)
-        ctx._host.copy_(ctx._recs, non_blocking=True)
-        torch.cuda.current_stream(ctx.device).synchronize()
+    edev = getattr(engine, "device", None)
+    if hasattr(engine, "argmin_into") and edev is not None and edev.type == "cuda":
+        rec = ctx.record_buffer(edev)
+        engine.argmin_into(c, thr, r0, r1, rec)
+        if ctx.device.type == "cuda":
+            dist.all_gather_into_tensor(ctx._recs, rec if rec.device == ctx.device else rec.to(ctx.device), group=ctx.group)
+            ctx._host.copy_(ctx._recs, non_blocking=True)
+            torch.cuda.current_stream(ctx.device).synchronize()
+        else:
+            mine = rec.cpu()                                   # synchronises the engine's stream
+            dist.all_gather_into_tensor(ctx._host, mine, group=ctx.group)
         recs = ctx._host.numpy().reshape(ctx.world, 4)
         if not (recs[:, 0] == 2).any():
             return _best_of_records(recs)

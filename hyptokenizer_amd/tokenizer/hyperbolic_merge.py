@@ -414,6 +414,25 @@ class HyperbolicTokenizer:
         unk = self.token2idx.get("<unk>", 3)
         return [self.token2idx.get(t, unk) for t in self.tokenize(text)]
 
+    # batch forms on the GPU (hm_tokenize_batch): what scripts/benchmark_efficiency.py:58-94 does line by line
+    def _batch_encoder(self):
+        if not hasattr(self, "_merge_rules"):       # built once and kept, like the reference's cache (:424-428)
+            self._merge_rules = {(a, b): ab for a, b, ab in self.merge_history}
+        enc = getattr(self, "_encoder", None)
+        if enc is None or enc[0] is not self._merge_rules or enc[1] != len(self.token2idx):
+            from .batch_encoder import BatchEncoder
+            enc = (self._merge_rules, len(self.token2idx), BatchEncoder(self._merge_rules, self.token2idx, self.device))
+            self._encoder = enc
+        return enc[2]
+
+    def tokenize_batch(self, texts: List[str]) -> List[List[str]]:
+        """``[self.tokenize(t) for t in texts]`` in one kernel launch."""
+        return self._batch_encoder().tokenize_batch(texts)
+
+    def encode_batch(self, texts: List[str]) -> List[List[int]]:
+        """``[self.encode(t) for t in texts]`` in one kernel launch."""
+        return self._batch_encoder().encode_batch(texts)
+
     def decode(self, indices: List[int]) -> str:
         return "".join(self.vocab[k] for k in indices)
 

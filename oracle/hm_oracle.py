@@ -262,3 +262,39 @@ def num_threads() -> int:
 
 def set_num_threads(n: int) -> None:
     lib().hmo_set_num_threads(n)
+
+
+# --------------------------------------------------------------------------------------------------
+# tokenize / encode (tokenizer/hyperbolic_merge.py:414-459): plain Python, as the reference's is
+# --------------------------------------------------------------------------------------------------
+def merge_rules(merge_history) -> dict:
+    """{(old1, old2): new}; a later entry for the same pair replaces the earlier one (:425-428)."""
+    rules = {}
+    for old1, old2, new in merge_history:
+        rules[(old1, old2)] = new
+    return rules
+
+
+def tokenize(rules: dict, text: str, count_passes: bool = False):
+    """Repeated left-to-right passes; a hit rewrites position i, removes i + 1 and stays at i (:430-446)."""
+    tokens = list(text)
+    passes = 0
+    changed = True
+    while changed:
+        changed = False
+        passes += 1
+        i = 0
+        while i < len(tokens) - 1:
+            hit = rules.get((tokens[i], tokens[i + 1]))
+            if hit is not None:
+                tokens[i] = hit
+                del tokens[i + 1]
+                changed = True
+            else:
+                i += 1
+    return (tokens, passes) if count_passes else tokens
+
+
+def encode(rules: dict, token2idx: dict, text: str) -> list:
+    unk = token2idx.get("<unk>", 3)        # :459
+    return [token2idx.get(t, unk) for t in tokenize(rules, text)]

@@ -11,7 +11,7 @@ Two oracle modes:
               ``embedding.lorentz_model.minkowski_dot`` negated (fixes distance/log_map) and
               ``batch_distance`` invoked as ``orig(x, -y, c)`` (it inlines its own dot product).
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [reference|lorentz|all] [all|g5]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [reference|lorentz|all] [all|g5|g6]
 """
 from __future__ import annotations
 
@@ -485,6 +485,50 @@ def g5_enhanced(mode: str) -> None:
         json.dump(meta, f, indent=1, ensure_ascii=False)
 
 
+# ---------------------------------------------------------------------------------------------
+# G6: tokenize / encode / decode (hyperbolic_merge.py:414-471) on lines of the reference's own
+# data/processed/wikitext103/test.txt, with a tokenizer trained by the reference's CLI function
+# ---------------------------------------------------------------------------------------------
+def g6_tokenize(mode: str) -> None:
+    import scripts.train_hyperbolic_tokenizer as T
+    vocab_path = os.path.join(REF, "data/processed/wiki/vocab_initial.txt")
+    with tempfile.TemporaryDirectory() as td:
+        T.train_tokenizer(vocab_path=vocab_path, output_dir=td, embedding_dim=5, curvature=1.0, merge_threshold=0.1,
+                          merge_steps=60, log_every=20, target_vocab_size=500, seed=42, use_fast_tokenizer=True, no_faiss=True)
+        tok = FM.FastHyperbolicTokenizer.load(td, device=torch.device("cpu")) if hasattr(FM.FastHyperbolicTokenizer, "load") else None
+        vocab = json.load(open(os.path.join(td, "vocab.json")))
+        merges = json.load(open(os.path.join(td, "merges.json")))
+    # a few hand-made rules on top, so that multi-level merges occur in ordinary text (th, he, the, in, ing, ...)
+    extra = [("t", "h", "th"), ("h", "e", "he"), ("th", "e", "the"), ("i", "n", "in"), ("in", "g", "ing"), ("e", "r", "er"),
+             ("a", "n", "an"), ("an", "d", "and"), ("o", "n", "on"), ("r", "e", "re"), ("e", "d", "ed"), (" ", "t", " t"),
+             (" t", "he", " the"), ("s", " ", "s "), ("e", "s", "es"), ("t", "i", "ti"), ("ti", "on", "tion")]
+    X = lorentz_table(len(vocab), 5, seed=1, scale=0.05)
+    tok = HM.HyperbolicTokenizer(vocab=list(vocab), embeddings=torch.nn.Parameter(X), device=torch.device("cpu"),
+                                 max_vocab_size=len(vocab) + 8, use_approximate_search=False)
+    tok.merge_history = [tuple(m) for m in merges] + extra
+    for (_a, _b, ab) in extra:
+        if ab not in tok.token2idx:
+            tok.vocab.append(ab)
+            tok.token2idx[ab] = len(tok.vocab) - 1
+    lines = []
+    with open(os.path.join(REF, "data/processed/wikitext103/test.txt"), encoding="utf-8") as f:
+        for line in f:
+            line = line.strip()
+            if len(line) > 40:
+                lines.append(line[:240])
+            if len(lines) == 24:
+                break
+    lines += ["", "a", "the", "ththththe", "in ing inging", "zzz \u4e2d\u6587 the", "tion" * 8]
+    out = {
+        "vocab": tok.vocab, "merges": [list(m) for m in tok.merge_history], "lines": lines,
+        "tokens": [tok.tokenize(t) for t in lines],
+        "ids": [tok.encode(t) for t in lines],
+    }
+    out["decoded"] = [tok.decode(i) for i in out["ids"]]
+    with open(os.path.join(HERE, f"g6_tokenize_{mode}.json"), "w") as f:
+        json.dump(out, f, ensure_ascii=False)
+
+
 def main() -> None:
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     only = sys.argv[2] if len(sys.argv) > 2 else "all"      # e.g. "g5": regenerate one family
@@ -494,6 +538,10 @@ def main() -> None:
         if only == "g5":
             g5_enhanced(mode)
             print(f"[{mode}] g5 done", flush=True)
+            continue
+        if only == "g6":
+            g6_tokenize(mode)
+            print(f"[{mode}] g6 done", flush=True)
             continue
         g1_primitives(mode)
         print(f"[{mode}] g1 done", flush=True)
@@ -505,6 +553,8 @@ def main() -> None:
         print(f"[{mode}] cli done", flush=True)
         g5_enhanced(mode)
         print(f"[{mode}] g5 done", flush=True)
+        g6_tokenize(mode)
+        print(f"[{mode}] g6 done", flush=True)
     set_mode("reference")
 
 

@@ -84,3 +84,58 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_process_run(world):
         assert p.exitcode == 0
     for r in range(world):
         assert results[r] == ref, r
+
+
+def _nccl_worker(rank, world, port, q):
+    os.environ["TQDM_DISABLE"] = "1"
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from hyptokenizer_amd.sharding import ShardContext
+        from hyptokenizer_amd.synthetic import cjk_vocab, lorentz_table
+        from hyptokenizer_amd.tokenizer.fast_hyperbolic_merge import FastHyperbolicTokenizer
+        from hyptokenizer_amd.tokenizer.hyperbolic_merge import HyperbolicTokenizer
+        dev = torch.device("cuda", rank)
+        ctx = ShardContext(device=dev)
+        X = lorentz_table(N, D, seed=42, scale=0.05)
+        tok = HyperbolicTokenizer(cjk_vocab(N), torch.nn.Parameter(X.clone()), merge_threshold=THR, device=dev, max_vocab_size=N + 512,
+                                  sign_convention="lorentz", shard=ctx)
+        tok.optimize_merges(steps=40, log_every=10 ** 9)
+        import random
+        random.seed(42)
+        ftok = FastHyperbolicTokenizer(cjk_vocab(N), torch.nn.Parameter(X.clone()), merge_threshold=THR, device=dev,
+                                       max_vocab_size=N + 512, sign_convention="lorentz", shard=ctx, cache_size=500)
+        ftok.optimize_merges(steps=230, log_every=1000)
+        q.put((rank, {"std_merges": list(tok.merge_history), "fast_merges": list(ftok.merge_history),
+                      "std_rows": tok.embeddings.data[N:tok.current_vocab_size].cpu().numpy().view(np.uint32).tolist()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl_when_two_gpus_are_visible():
+    """N > 1 over RCCL (backend "nccl", one GPU per rank): runs wherever at least two devices are visible (the
+    driver's 8-GPU node), skipped on the one-GPU test box.  Same comparisons as the shared-GPU gloo test."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible GPUs (RCCL); the one-GPU box covers the same logic over gloo")
+    os.environ["TQDM_DISABLE"] = "1"
+    ref = _run(None)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert results[r]["std_merges"] == ref["std_merges"] and results[r]["fast_merges"] == ref["fast_merges"], r
+        assert results[r]["std_rows"] == ref["std_rows"], r
