@@ -88,8 +88,8 @@ def load() -> C.CDLL:
     L.hm_randperm_prefix.argtypes = [vp, pi32, C.POINTER(C.c_uint32), i64, i32, i64, vp]
     L.hm_tokenize_table_capacity.restype = i64
     L.hm_tokenize_table_capacity.argtypes = [i64]
-    L.hm_tokenize_build_table.argtypes = [vp, vp, vp, i64, i64, vp, vp, i64, vp]
-    L.hm_tokenize_batch.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp]
+    L.hm_tokenize_build_table.argtypes = [vp, vp, vp, i64, vp, i64]
+    L.hm_tokenize_batch.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp]
     L.hm_engine_destroy.argtypes = [vp]
     L.hm_set_table.argtypes = [vp, vp, i64, i64, vp]
     L.hm_update_rows.argtypes = [vp, vp, i64, i64, i64, vp]

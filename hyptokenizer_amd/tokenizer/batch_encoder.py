@@ -44,6 +44,8 @@ class BatchEncoder:
         for s, k in sym.items():
             self.strings[k] = s
         n_sym = len(sym)
+        if n_sym >= (1 << 21) - 1:
+            raise ValueError(f"{n_sym} distinct strings: the rule table packs symbols into 21 bits")
         # character -> symbol (dense over the code space: one gather per batch)
         lut = -(2 + np.arange(_N_CODEPOINTS, dtype=np.int64))
         for s, k in sym.items():
@@ -59,16 +61,12 @@ class BatchEncoder:
         right = np.fromiter((sym[b] for (_a, b) in rules), dtype=np.int32, count=n_rules)
         merged = np.fromiter((sym[ab] for ab in rules.values()), dtype=np.int32, count=n_rules)
         cap = int(self._L.hm_tokenize_table_capacity(n_rules))
-        keys = np.empty(cap, dtype=np.uint64)
-        vals = np.empty(cap, dtype=np.int32)
-        flags = np.zeros(max(n_sym, 1), dtype=np.uint8)
-        _lib.check(self._L.hm_tokenize_build_table(left.ctypes.data, right.ctypes.data, merged.ctypes.data, n_rules, n_sym,
-                                                   keys.ctypes.data, vals.ctypes.data, cap, flags.ctypes.data))
+        table = np.empty(cap, dtype=np.uint64)
+        _lib.check(self._L.hm_tokenize_build_table(left.ctypes.data, right.ctypes.data, merged.ctypes.data, n_rules,
+                                                   table.ctypes.data, cap))
         self.capacity = cap
         self.n_rules = n_rules
-        self._keys = torch.from_numpy(keys.view(np.int64)).to(self.device)
-        self._vals = torch.from_numpy(vals).to(self.device)
-        self._flags = torch.from_numpy(flags).to(self.device)
+        self._table = torch.from_numpy(table.view(np.int64)).to(self.device)      # torch allocations are 256-byte aligned
 
     # ------------------------------------------------------------------------------------------
     def symbols(self, texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
@@ -90,7 +88,7 @@ class BatchEncoder:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._L.hm_tokenize_batch(
             sym.data_ptr() if sym.numel() else None, offsets.data_ptr(), order.data_ptr() if order is not None else None, n,
-            self._keys.data_ptr(), self._vals.data_ptr(), self.capacity, self._flags.data_ptr(),
+            self._table.data_ptr(), self.capacity,
             out.data_ptr() if out.numel() else None, out_len.data_ptr(), passes.data_ptr() if passes is not None else None,
             C.c_void_p(stream)))
         return out, out_len[:n], (passes[:n] if passes is not None else None)
@@ -102,6 +100,8 @@ class BatchEncoder:
             return np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int64)
         sym_h, off_h = self.symbols(texts)
         lens_h = np.diff(off_h)
+        if lens_h.max() >= 2 ** 31:
+            raise ValueError("a line of 2^31 or more characters")
         with torch.cuda.device(self.device):
             sym = torch.from_numpy(sym_h).to(self.device)
             off = torch.from_numpy(off_h).to(self.device)
@@ -129,11 +129,17 @@ class BatchEncoder:
         lst = strs.tolist()
         return [lst[int(e - k):int(e)] for e, k in zip(ends, lens)]
 
-    def encode_batch(self, texts: Sequence[str]) -> List[List[int]]:
+    def encode_arrays(self, texts: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
+        """``encode`` of every line as (ids of all lines concatenated, offsets[n + 1]) -- no Python lists."""
         flat, lens = self._tokens(texts)
         ids = np.full(flat.shape[0], self.unk, dtype=np.int64)
         known = flat >= 0
         ids[known] = self._sym2vocab[flat[known]]
-        ends = np.cumsum(lens)
+        offsets = np.zeros(len(texts) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        return ids, offsets
+
+    def encode_batch(self, texts: Sequence[str]) -> List[List[int]]:
+        ids, offsets = self.encode_arrays(texts)
         lst = ids.tolist()
-        return [lst[int(e - k):int(e)] for e, k in zip(ends, lens)]
+        return [lst[int(b):int(e)] for b, e in zip(offsets[:-1], offsets[1:])]

@@ -204,19 +204,22 @@ int hm_randperm_prefix(uint32_t* mt_state, int32_t* left, uint32_t* next, int64_
  * Replaces: tokenizer/hyperbolic_merge.py:414-446 (and with it encode :448-459) as driven per line by
  * scripts/benchmark_efficiency.py:58-94.
  *
+ * Symbols of rules lie in [0, 2^21 - 1) (two million distinct strings).
+ *
  * hm_tokenize_table_capacity / hm_tokenize_build_table are host-only: they build the open-addressing rule table
- * {(left, right) -> merged} (a later rule for the same pair replaces the earlier one, as dict assignment does,
- * :425-428) and the per-symbol operand flags; the caller copies the three arrays to the device. */
+ * {(left, right) -> merged} as `capacity` 8-byte entries left:21 | right:21 | merged+1:22 in buckets of two (a later
+ * rule for the same pair replaces the earlier one, as dict assignment does, :425-428); the caller copies the
+ * `capacity` words to 16-byte-aligned device memory. */
 int64_t hm_tokenize_table_capacity(int64_t n_rules);
-int hm_tokenize_build_table(const int32_t* left, const int32_t* right, const int32_t* merged, int64_t n_rules, int64_t n_sym,
-                            uint64_t* keys_out, int32_t* vals_out, int64_t capacity, uint8_t* flags_out);
-/* sym_dev: symbols of all lines concatenated; offsets_dev[n_lines + 1]; order_dev: optional permutation of the
- * lines (thread t handles line order_dev[t]; longest-first keeps the lanes of a wave alike), may be NULL.
- * Line l's tokens are written to out_dev[offsets[l] .. offsets[l] + out_len_dev[l]); passes_dev (optional)
- * receives the number of passes the reference's while-loop runs.  Asynchronous on `stream`. */
+int hm_tokenize_build_table(const int32_t* left, const int32_t* right, const int32_t* merged, int64_t n_rules,
+                            uint64_t* table_out, int64_t capacity);
+/* sym_dev: symbols of all lines concatenated (each line < 2^31 symbols); offsets_dev[n_lines + 1]; order_dev:
+ * optional permutation of the lines (lane t handles line order_dev[t]; longest-first keeps the 64 lines of a wave
+ * alike), may be NULL.  Line l's tokens are written to out_dev[offsets[l] .. offsets[l] + out_len_dev[l]);
+ * passes_dev (optional) receives the number of passes the reference's while-loop runs.  Asynchronous on `stream`. */
 int hm_tokenize_batch(const int32_t* sym_dev, const int64_t* offsets_dev, const int64_t* order_dev, int64_t n_lines,
-                      const uint64_t* keys_dev, const int32_t* vals_dev, int64_t capacity, const uint8_t* flags_dev,
-                      int32_t* out_dev, int32_t* out_len_dev, int32_t* passes_dev, void* stream);
+                      const uint64_t* table_dev, int64_t capacity, int32_t* out_dev, int32_t* out_len_dev,
+                      int32_t* passes_dev, void* stream);
 
 /* Dense distance block between two arbitrary device arrays: out_dev[n1, n2].
  * Replaces: batch_distance / batch_distance_optimized (embedding/lorentz_model.py:141-210) and

@@ -74,7 +74,7 @@ def test_device_functions_refuse_cpu_tensors():
 
 def test_tokenize_rule_table_builder_is_host_only():
     """hm_tokenize_build_table needs no GPU: every rule is found by the kernel's probe sequence, a repeated pair keeps
-    the LAST result (dict assignment, hyperbolic_merge.py:425-428), operand flags are set."""
+    the LAST result (dict assignment, hyperbolic_merge.py:425-428)."""
     import numpy as np
     from hyptokenizer_amd import _lib
     L = _lib.load()
@@ -85,27 +85,34 @@ def test_tokenize_rule_table_builder_is_host_only():
     merged = rng.integers(0, n_sym, n_rules).astype(np.int32)
     left[-1], right[-1] = left[0], right[0]                    # repeated pair
     cap = int(L.hm_tokenize_table_capacity(n_rules))
-    assert cap >= 2 * n_rules + 2 and cap & (cap - 1) == 0
-    keys = np.empty(cap, dtype=np.uint64)
-    vals = np.empty(cap, dtype=np.int32)
-    flags = np.empty(n_sym, dtype=np.uint8)
-    assert L.hm_tokenize_build_table(left.ctypes.data, right.ctypes.data, merged.ctypes.data, n_rules, n_sym,
-                                     keys.ctypes.data, vals.ctypes.data, cap, flags.ctypes.data) == 0
+    assert cap >= 8 * n_rules and cap & (cap - 1) == 0
+    table = np.empty(cap, dtype=np.uint64)
+    assert L.hm_tokenize_build_table(left.ctypes.data, right.ctypes.data, merged.ctypes.data, n_rules, table.ctypes.data, cap) == 0
     want = {}
     for a, b, ab in zip(left.tolist(), right.tolist(), merged.tolist()):
         want[(a, b)] = ab
-    shift = 64 - (cap.bit_length() - 1)
+    n_buckets = cap // 2
+    shift = 64 - (n_buckets.bit_length() - 1)
+    tab = [int(x) for x in table]
+    longest = 0
     for (a, b), ab in want.items():
-        key = (a << 32) | b
-        s = ((key * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)) >> shift
-        while int(keys[s]) != key:
-            assert int(keys[s]) != (1 << 64) - 1
-            s = (s + 1) & (cap - 1)
-        assert int(vals[s]) == ab
-    assert int((keys != np.uint64((1 << 64) - 1)).sum()) == len(want)
-    assert all(flags[a] & 1 for a in left.tolist()) and all(flags[b] & 2 for b in right.tolist())
-    # capacity that is too small or not a power of two is refused
-    assert L.hm_tokenize_build_table(left.ctypes.data, right.ctypes.data, merged.ctypes.data, n_rules, n_sym,
-                                     keys.ctypes.data, vals.ctypes.data, 1024, flags.ctypes.data) == -1
+        tag = (a << 21) | b
+        s = ((tag * 0x9E3779B97F4A7C15) & ((1 << 64) - 1)) >> shift
+        steps = 1
+        while True:
+            e0, e1 = tab[2 * s], tab[2 * s + 1]
+            hit = [e for e in (e0, e1) if e != 0 and e >> 22 == tag]
+            if hit:
+                assert (hit[0] & ((1 << 22) - 1)) - 1 == ab
+                break
+            assert e0 != 0 and e1 != 0          # a bucket with a free slot ends the kernel's probe sequence
+            s = (s + 1) & (n_buckets - 1)
+            steps += 1
+        longest = max(longest, steps)
+    assert sum(1 for e in tab if e != 0) == len(want) and longest <= 3
+    # capacity that is too small or not a power of two is refused, and so are symbols beyond 21 bits
+    assert L.hm_tokenize_build_table(left.ctypes.data, right.ctypes.data, merged.ctypes.data, n_rules, table.ctypes.data, 1024) == -1
+    big = np.array([1 << 21], dtype=np.int32)
+    assert L.hm_tokenize_build_table(big.ctypes.data, big.ctypes.data, big.ctypes.data, 1, table.ctypes.data, cap) == -1
     # no GPU here: the batch call has nothing to run on, but its argument check is reachable
-    assert L.hm_tokenize_batch(None, None, None, 5, None, None, cap, None, None, None, None, None) == -1
+    assert L.hm_tokenize_batch(None, None, None, 5, None, cap, None, None, None, None) == -1
