@@ -393,7 +393,7 @@ def main() -> None:
     vocab = cjk_vocab(V)
     steps_total = args.steps + args.warmup
     tok = HyperbolicTokenizer(vocab, torch.nn.Parameter(X), curvature=CURV, merge_threshold=THR, device=device,
-                              max_vocab_size=V + steps_total + 64, sign_convention="lorentz", shard=shard)
+                              max_vocab_size=V + steps_total + 192, sign_convention="lorentz", shard=shard)
     eng = tok._get_engine()                      # builds the scan image: inputs resident before timing
     torch.cuda.synchronize()
 
@@ -418,6 +418,20 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     merges_done = len(tok.merge_history) - args.warmup
     tot = eng.scan_totals()
+    # instrumented batch (not part of `value`): one more 64-step device batch with a HIP event pair around EVERY scan
+    # launch and around the batch -> the roofline's mean launch duration over 64 launches and the per-step overhead
+    # (everything in a step that is not the scan: launch gaps, tail kernel with the merge), both from the same batch
+    loop_t = None
+    if world == 1 and shard is None:
+        eng.scan_totals(reset=True)
+        eng.debug_time_loops(True)
+        tok.optimize_merges(steps=64, log_every=10 ** 9)
+        torch.cuda.synchronize()
+        lt = eng.last_loop_timing()
+        eng.debug_time_loops(False)
+        if lt["steps"] == 64:
+            loop_t = lt
+            tot = eng.scan_totals()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -522,7 +536,11 @@ def main() -> None:
                                    f"fp32, lorentz sign, thr={THR}, c={CURV}, scale={SCALE}, seed={SEED}",
                        "vocab": V, "dim": D, "merge_threshold": THR, "parallelism": f"rows sharded over {world} rank(s)"},
             "pairwise_dist_GBps_effective": (n_mid * n_mid * 4.0) / (scan_ms_per_step * 1e-3) / 1e9,
-            "step_overhead_ms": 1e3 * elapsed / max(args.steps, 1) - avg_ms,
+            "step_overhead_ms": ((loop_t["batch_ms"] - loop_t["scan_ms"]) / loop_t["steps"]) if loop_t
+                                else 1e3 * elapsed / max(args.steps, 1) - avg_ms,
+            "step_overhead_note": ("instrumented 64-step device batch after the timed region: (batch wall time on the device - sum "
+                                   f"of its 64 scan launches) / 64; batch {loop_t['batch_ms']:.3f} ms, scans {loop_t['scan_ms']:.3f} ms"
+                                   if loop_t else "ms_per_step - mean scan launch"),
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": ("bytes per launch past the XCD L2s (FETCH_SIZE corrected x2 + WRITE_SIZE) from "
@@ -531,7 +549,8 @@ def main() -> None:
                          "kernel": kernel_name, "avg_launch_ms": avg_ms,
                          "flops_per_launch": flops_per_launch, "timed_launches": launches,
                          "note": "flops = N(N-1)(d+1) algorithmic (triangle); peak = dense MFMA peak of the prefilter's dtype; "
-                                 "one scan launch per 64-step device batch carries the HIP events"},
+                                 "avg_launch_ms = mean over the 64 scan launches of an instrumented device batch run right after the timed region "
+                                 "(HIP events on the launch stream around every launch)"},
             "fast_path": fast,
             "incremental": incr,
             "legs": legs,

@@ -189,6 +189,11 @@ struct hm_engine {
     int64_t prev_k = 0, prev_n = 0;
     float prev_thr = 0.f;
     bool debug_cut = false;               // hm_debug_force_cut: the next top-k starts from last_cut_bits as given
+    // hm_debug_time_loops: an event pair around EVERY scan of a device-resident batch and around the batch itself
+    bool time_loops = false;
+    std::vector<hipEvent_t> loop_evs;     // 2 * HM_LOOP_MAX_STEPS + 2, created on first use
+    float last_batch_ms = 0.f, last_batch_scan_ms = 0.f;
+    int64_t last_batch_steps = 0;
     // stats
     float last_scan_ms = 0.f;
     int64_t last_pairs = 0, last_emitted = 0;

@@ -160,6 +160,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     if (e->h_sorted) (void)hipHostFree(e->h_sorted);
     if (e->h_batch) (void)hipHostFree(e->h_batch);
     if (e->ev_batch) (void)hipEventDestroy(e->ev_batch);
+    for (hipEvent_t ev : e->loop_evs) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     delete e;
@@ -297,5 +298,29 @@ extern "C" int hm_debug_force_cut(hm_engine* e, uint32_t cut_bits, int64_t k, fl
     e->last_cut_k = k;
     e->last_cut_c = c;
     e->debug_cut = true;
+    return HM_OK;
+}
+
+// Measurement aid (bench.py): with on != 0 the device-resident loops record an event pair around EVERY scan launch of a
+// batch and around the batch as a whole; hm_last_loop_timing returns the sums of the last batch.  The extra event
+// packets cost a microsecond or two per step, so the figure the bench reports as throughput is taken with this off.
+extern "C" int hm_debug_time_loops(hm_engine* e, int on)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_debug_time_loops: engine is NULL");
+    HM_HIP(hipSetDevice(e->device));
+    if (on && e->loop_evs.empty()) {
+        e->loop_evs.resize(2 * HM_LOOP_MAX_STEPS + 2, nullptr);
+        for (auto& ev : e->loop_evs) HM_HIP(hipEventCreate(&ev));
+    }
+    e->time_loops = on != 0;
+    return HM_OK;
+}
+
+extern "C" int hm_last_loop_timing(const hm_engine* e, float* batch_ms, float* scan_ms, int64_t* steps)
+{
+    if (!e || !batch_ms || !scan_ms || !steps) return HM_E_ARG;
+    *batch_ms = e->last_batch_ms;
+    *scan_ms = e->last_batch_scan_ms;
+    *steps = e->last_batch_steps;
     return HM_OK;
 }

@@ -86,6 +86,8 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
     bool armed = e->armed && e->armed_rb == 0 && e->armed_re == -1;
     e->armed = false;
     int64_t timed_pairs = 0;
+    const bool time_all = e->time_loops && !e->loop_evs.empty();
+    int64_t all_pairs[HM_LOOP_MAX_STEPS];
     for (int64_t k = 0; k < steps; ++k) {
         ScanArgs a; dim3 grid;
         if (!hm_prepare_scan(e, b, 0, -1, a, grid)) return hm_fail(e, HM_E_STATE, "hm_std_merge_steps: empty scan");
@@ -94,9 +96,16 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
             int rc0 = hm_launch_seed_init(e, a, s);
             if (rc0) { e->n = n0; return rc0; }
         }
-        // the last scan of the batch carries the timing events (one event pair per engine)
+        // the last scan of the batch carries the timing events (one event pair per engine); in the measurement mode of
+        // hm_debug_time_loops every scan has its own pair
         const bool timed = (k == steps - 1);
-        HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, timed ? e->ev0 : nullptr, timed ? e->ev1 : nullptr));
+        if (time_all) {
+            if (k == 0) HM_HIP(hipEventRecord(e->loop_evs[2 * HM_LOOP_MAX_STEPS], s));
+            HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, e->loop_evs[2 * k], e->loop_evs[2 * k + 1]));
+            all_pairs[k] = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
+        } else {
+            HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, timed ? e->ev0 : nullptr, timed ? e->ev1 : nullptr));
+        }
         if (timed) timed_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
         MergeFuse mf;
         mf.X = X_dev; mf.ld = ld; mf.new_row = e->n; mf.c = c;
@@ -106,12 +115,28 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
         armed = true;
         e->n += 1;                            // optimistic: corrected below when the batch stopped early
     }
+    if (time_all) HM_HIP(hipEventRecord(e->loop_evs[2 * HM_LOOP_MAX_STEPS + 1], s));
     HM_HIP(hipMemcpyAsync(e->h->loop_recs, e->d_loop_recs, sizeof(ArgminRec) * (size_t)steps, hipMemcpyDeviceToHost, s));
     HM_HIP(hipStreamSynchronize(s));
     hm_unpack_recs(e->h->loop_recs, steps, rec_out, done);
     e->n = n0 + *done;
     e->armed = (*done == steps);
     e->armed_rb = 0; e->armed_re = -1;
+    if (time_all) {
+        e->last_batch_ms = e->last_batch_scan_ms = 0.f;
+        e->last_batch_steps = 0;
+        if (*done == steps) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e->loop_evs[2 * HM_LOOP_MAX_STEPS], e->loop_evs[2 * HM_LOOP_MAX_STEPS + 1]) == hipSuccess) e->last_batch_ms = ms;
+            for (int64_t k = 0; k < steps; ++k) {
+                if (hipEventElapsedTime(&ms, e->loop_evs[2 * k], e->loop_evs[2 * k + 1]) != hipSuccess) continue;
+                e->last_batch_scan_ms += ms;
+                e->tot_scan_ms += ms; e->tot_pairs += all_pairs[k]; e->tot_launches += 1;
+            }
+            e->last_batch_steps = steps;
+        }
+        return HM_OK;
+    }
     if (*done == steps) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) {
@@ -146,10 +171,19 @@ struct IncrArgs {
 // also stores it and writes the step's record), (3) scans its slice of the image against the new row and publishes its
 // nearest partner with ONE 64-bit atomicMin.  The fold of THIS step's row pass happens at the start of the next launch
 // (or on the host after the last one), so there is no ticket, no fence and no final block.
-__global__ __launch_bounds__(512) void hm_incr_step_kernel(const IncrArgs a)
+#define HM_INCR_WAVES 2
+__global__ __launch_bounds__(64 * HM_INCR_WAVES) void hm_incr_step_kernel(const IncrArgs a)
 {
+    extern __shared__ __align__(16) float tiles[];
     __shared__ MidScratch ms;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* tile = tiles + wv * HM_TILE_ROWS * a.RS;
+    // the first tile of partner rows does not depend on which pair is merged: its loads are in flight during the fold
+    // of the previous step and the midpoint
+    const int64_t nt = (a.new_row + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
+    int64_t tl = (int64_t)blockIdx.x * HM_INCR_WAVES + wv;
+    TileRegs tr;
+    if (tl < nt) hm_tile_load(a.img, a.RS, tl * HM_TILE_ROWS, a.new_row, tr, lane);
     LoopState* loop = a.loop;
     const uint32_t stop = loop->stop;
     ArgminRec best = loop->best;
@@ -185,30 +219,21 @@ __global__ __launch_bounds__(512) void hm_incr_step_kernel(const IncrArgs a)
         }
     }
     __syncthreads();
-    // ---- nearest partner of the new row among rows [0, new_row): a half-wave per partner row ----
+    // ---- nearest partner of the new row among rows [0, new_row): lane l of a wave takes row l of the wave's tile ----
     unsigned long long key = ~0ull;
-    {
-        const int d = a.d, RS = a.RS, t = lane & 31;
-        const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
-        const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-        const float x_time = ms.so[0];
-        for (int64_t base = (hw & ~(int64_t)1) * HM_GATHER; base < a.new_row; base += nhw * HM_GATHER) {
-            const int64_t mybase = base + (hw & 1) * HM_GATHER;
-            const float u = hm_halfwave_gather(lane, [&](int k) {
-                const int64_t r = mybase + k < a.new_row ? mybase + k : a.new_row - 1;
-                const float* ri = a.img + r * RS;
-                const float S = hm_halfwave_sum(d, lane, [&](int e) { return ri[hm_img_off(e)] * ms.so[1 + e]; });
-                const float tp = ri[RS - 4] * x_time;
-                const float mm = tp - S;
-                return a.sign_mode ? mm : -mm;
-            });
-            const int64_t i = mybase + t;
-            const float dd = hm::dist_from_u(u, a.sqrt_c);
-            if (t < HM_GATHER && i < a.new_row && dd < a.thr) {
-                const unsigned long long k64 = ((unsigned long long)hm::fbits(dd) << 32) | (unsigned long long)(uint32_t)i;
-                key = k64 < key ? k64 : key;
-            }
+    for (; tl < nt; tl += (int64_t)gridDim.x * HM_INCR_WAVES) {
+        hm_tile_store(tile, a.RS, tr, lane);
+        hm_wave_lds_sync();
+        const int64_t nxt = tl + (int64_t)gridDim.x * HM_INCR_WAVES;
+        if (nxt < nt) hm_tile_load(a.img, a.RS, nxt * HM_TILE_ROWS, a.new_row, tr, lane);
+        const float u = hm_tile_u(tile, a.RS, a.d, ms.so, a.sign_mode, lane);
+        const int64_t i = tl * HM_TILE_ROWS + lane;
+        const float dd = hm::dist_from_u(u, a.sqrt_c);
+        if (i < a.new_row && dd < a.thr) {
+            const unsigned long long k64 = ((unsigned long long)hm::fbits(dd) << 32) | (unsigned long long)(uint32_t)i;
+            key = k64 < key ? k64 : key;
         }
+        hm_wave_lds_sync();
     }
     key = hm_wave_min_u64(key);
     if (lane == 0 && key != ~0ull) atomicMin(&loop->rowkey[a.step], key);
@@ -241,11 +266,20 @@ extern "C" int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_de
     a.img = e->img; a.img16 = e->img16; a.RS = e->RS; a.d = e->d; a.KS = e->KS; a.sign_mode = e->sign_mode;
     a.c = c; a.sqrt_c = sqrtf(c); a.thr = thr; a.X = X_dev; a.ld = ld; a.len = e->d_len; a.loop = e->d_loop;
     a.rmax2_bits = e->d_rmax2;
+    const size_t lds = sizeof(float) * (size_t)HM_INCR_WAVES * HM_TILE_ROWS * e->RS;
+    static bool attr_done = false;
+    if (!attr_done) {
+        HM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hm_incr_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(float) * (size_t)HM_INCR_WAVES * HM_TILE_ROWS * 4 * HM_TILE_MAXQ)));
+        attr_done = true;
+    }
     for (int64_t k = 0; k < steps; ++k) {
         a.new_row = n0 + k;
         a.step = (int)k;
         a.rec_ring = e->d_loop_recs + k;
-        hipLaunchKernelGGL(hm_incr_step_kernel, dim3(HM_ROWPASS_BLOCKS), dim3(512), 0, s, a);
+        const int64_t nt = (a.new_row + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((nt + HM_INCR_WAVES - 1) / HM_INCR_WAVES, 512));
+        hipLaunchKernelGGL(hm_incr_step_kernel, dim3(grid), dim3(64 * HM_INCR_WAVES), lds, s, a);
         HM_HIP(hipGetLastError());
     }
     HM_HIP(hipMemcpyAsync(e->h->loop_recs, e->d_loop_recs, sizeof(ArgminRec) * (size_t)steps, hipMemcpyDeviceToHost, s));

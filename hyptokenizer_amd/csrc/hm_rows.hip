@@ -114,19 +114,29 @@ __global__ __launch_bounds__(256) void hm_pairdist_kernel(const float* __restric
     }
 }
 
-__global__ __launch_bounds__(256) void hm_rowvsall_kernel(const float* __restrict__ img, int RS, int d, int64_t row, int64_t n,
-                                                          float sqrt_c, int sign_mode, float* __restrict__ out)
+#define HM_ROWVS_WAVES 2
+__global__ __launch_bounds__(64 * HM_ROWVS_WAVES) void hm_rowvsall_kernel(const float* __restrict__ img, int RS, int d, int64_t row, int64_t n,
+                                                                          float sqrt_c, int sign_mode, float* __restrict__ out)
 {
-    const int lane = threadIdx.x & 63, t = lane & 31;
-    const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
-    const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    for (int64_t base = (hw & ~(int64_t)1) * HM_GATHER; base < n; base += nhw * HM_GATHER) {
-        const int64_t mybase = base + (hw & 1) * HM_GATHER;
-        const float u = hm_halfwave_gather(lane, [&](int k) {
-            const int64_t r = mybase + k < n ? mybase + k : n - 1;
-            return hm_img_u_halfwave(img, RS, d, row, r, sign_mode, lane);
-        });
-        if (t < HM_GATHER && mybase + t < n) out[mybase + t] = hm::dist_from_u(u, sqrt_c);
+    extern __shared__ __align__(16) float lds[];
+    float* xs = lds;                                           // the fixed row, reference column order
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* tile = lds + HM_MAX_D1 + 4 + wv * HM_TILE_ROWS * RS;   // (HM_MAX_D1 + 4) % 4 == 0: tiles stay 16-byte aligned
+    const int64_t nt = (n + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
+    int64_t tl = (int64_t)blockIdx.x * HM_ROWVS_WAVES + wv;
+    TileRegs tr;
+    if (tl < nt) hm_tile_load(img, RS, tl * HM_TILE_ROWS, n, tr, lane);
+    for (int k = threadIdx.x; k <= d; k += blockDim.x) xs[k] = k == 0 ? hm_img_time(img, RS, row) : hm_img_spatial(img, RS, row, k - 1);
+    __syncthreads();
+    for (; tl < nt; tl += (int64_t)gridDim.x * HM_ROWVS_WAVES) {
+        hm_tile_store(tile, RS, tr, lane);
+        hm_wave_lds_sync();
+        const int64_t nxt = tl + (int64_t)gridDim.x * HM_ROWVS_WAVES;
+        if (nxt < nt) hm_tile_load(img, RS, nxt * HM_TILE_ROWS, n, tr, lane);      // in flight while this tile is evaluated
+        const float u = hm_tile_u(tile, RS, d, xs, sign_mode, lane);
+        const int64_t r = tl * HM_TILE_ROWS + lane;
+        if (r < n) out[r] = hm::dist_from_u(u, sqrt_c);
+        hm_wave_lds_sync();
     }
 }
 
@@ -231,24 +241,34 @@ __global__ __launch_bounds__(256) void hm_coherence_kernel(const float* __restri
 // project_to_hyperboloid over rows [0, n_rows) of the caller's table in place (enhanced...:784-792): only
 // column 0 changes.  Rows below n_live also refresh the time slots of both images and the norm bounds.
 // 64 rows per block are staged through LDS with coalesced loads; a thread then runs its row's fmaf chain
-// (the canonical order of project is sequential) on LDS operands -- row stride d1 | 1: conflict-free.
+// (the canonical order of project is sequential) on LDS operands.
 __global__ __launch_bounds__(64) void hm_project_table_kernel(float* __restrict__ X, int64_t ld, int d, int64_t n_rows, float c,
                                                               float* __restrict__ img, int RS, unsigned char* __restrict__ img16, int KS,
                                                               int64_t n_live, uint32_t* __restrict__ rmax2_bits)
 {
     extern __shared__ float tile[];                           // 64 x stride
-    const int stride = d | 1;                                 // spatial part only, odd stride
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int rows = (int)(n_rows - r0 < 64 ? n_rows - r0 : 64);
     const int lane = threadIdx.x;
-    for (int q = lane; q < rows * d; q += 64) {
-        const int r = q / d, k = q - r * d;
-        tile[r * stride + k] = X[(r0 + r) * ld + 1 + k];
+    int stride, first;
+    if (ld == d + 1) {                                        // the reference's layout: rows back to back -> one flat copy
+        stride = (int)ld; first = 1;
+        const float* src = X + r0 * ld;
+        const int total = rows * (int)ld;
+#pragma unroll 8
+        for (int q = lane; q < total; q += 64) tile[q] = src[q];
+    } else {
+        stride = d | 1; first = 0;                            // spatial part only, odd stride
+        for (int q = lane; q < rows * d; q += 64) {
+            const int r = q / d, k = q - r * d;
+            tile[r * stride + k] = X[(r0 + r) * ld + 1 + k];
+        }
     }
     __syncthreads();
     float r2 = 0.0f, x0 = 0.0f;
     if (lane < rows) {
-        const float* tr = tile + lane * stride;
+        const float* tr = tile + lane * stride + first;
+#pragma unroll 4
         for (int k = 0; k < d; ++k) r2 = __builtin_fmaf(tr[k], tr[k], r2);
         const float rr = __builtin_sqrtf(r2);
         x0 = __builtin_sqrtf(1.0f + (c * rr) * rr);
@@ -401,8 +421,18 @@ extern "C" int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, floa
         return hm_fail(e, HM_E_ARG, "hm_row_vs_all: bad arguments");
     HM_HIP(hipSetDevice(e->device));
     if (n == 0) return HM_OK;
-    hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)std::min<int64_t>((n + 8 * HM_GATHER - 1) / (8 * HM_GATHER), 8192)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
-                       row, n, sqrtf(c), e->sign_mode, d_out_dev);
+    {
+        const size_t lds = sizeof(float) * ((size_t)HM_MAX_D1 + 4 + (size_t)HM_ROWVS_WAVES * HM_TILE_ROWS * e->RS);
+        static bool attr_done = false;
+        if (!attr_done) {
+            HM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hm_rowvsall_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(float) * ((size_t)HM_MAX_D1 + 4 + (size_t)HM_ROWVS_WAVES * HM_TILE_ROWS * 4 * HM_TILE_MAXQ))));
+            attr_done = true;
+        }
+        const int64_t nt = (n + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
+        hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)std::min<int64_t>((nt + HM_ROWVS_WAVES - 1) / HM_ROWVS_WAVES, 1024)), dim3(64 * HM_ROWVS_WAVES), lds,
+                           (hipStream_t)stream, e->img, e->RS, e->d, row, n, sqrtf(c), e->sign_mode, d_out_dev);
+    }
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
@@ -531,7 +561,7 @@ extern "C" int hm_project_table(hm_engine* e, float* X_dev, int64_t ld, int64_t 
     HM_HIP(hipSetDevice(e->device));
     if (n_rows == 0) return HM_OK;
     HM_HIP(hipMemsetAsync(e->d_rmax2, 0, sizeof(uint32_t) * 2, s));
-    const size_t lds = sizeof(float) * 64 * (size_t)(e->d | 1);
+    const size_t lds = sizeof(float) * 64 * (size_t)(e->d + 2);
     hipLaunchKernelGGL(hm_project_table_kernel, dim3((unsigned)((n_rows + 63) / 64)), dim3(64), lds, s, X_dev, ld, e->d, n_rows, c,
                        e->img, e->RS, e->img16, e->KS, e->n, e->d_rmax2);
     HM_HIP(hipGetLastError());

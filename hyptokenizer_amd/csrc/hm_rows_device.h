@@ -102,3 +102,50 @@ __device__ __forceinline__ void hm_wave_store_row(MidScratch& ms, float r2, int 
         *reinterpret_cast<uint4*>(img16 + ((int64_t)row * CH + cidx) * 16) = v;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// row tiles: one fixed row against 64 CONSECUTIVE image rows per wave
+// ------------------------------------------------------------------------------------------------
+// The image rows of a tile are one contiguous block of 64 * RS floats: the wave copies it to LDS with fully coalesced
+// 16-byte loads (RS / 4 of them per lane, all in flight together -- and issued BEFORE the fixed row is known, where
+// the caller has something else to do first), then lane l evaluates the canonical u of row r0 + l on its own, in
+// torch's reduction order (hm::torch_order_sum), out of LDS: RS / 4 is odd (hm_row_floats), so lane-private reads at
+// stride RS hit 64 different banks.  Against a half-wave per row this is a sixth of the memory instructions, no
+// shuffles, and the transcendental tail runs once per row on 64 rows at a time.
+#define HM_TILE_ROWS 64
+#define HM_TILE_MAXQ 33            // RS / 4 at d = 128
+
+struct TileRegs { uint4 q[HM_TILE_MAXQ]; };
+
+__device__ __forceinline__ void hm_tile_load(const float* __restrict__ img, int RS, int64_t r0, int64_t n, TileRegs& tr, int lane)
+{
+    const int64_t rows = n - r0 < HM_TILE_ROWS ? n - r0 : HM_TILE_ROWS;
+    const int total = rows > 0 ? (int)rows * (RS >> 2) : 0;
+    const uint4* src = reinterpret_cast<const uint4*>(img + r0 * RS);
+#pragma unroll
+    for (int i = 0; i < HM_TILE_MAXQ; ++i) {
+        const int j = lane + 64 * i;
+        tr.q[i] = j < total ? src[j] : make_uint4(0, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void hm_tile_store(float* tile, int RS, const TileRegs& tr, int lane)
+{
+    uint4* dst = reinterpret_cast<uint4*>(tile);
+    const int total = HM_TILE_ROWS * (RS >> 2);
+#pragma unroll
+    for (int i = 0; i < HM_TILE_MAXQ; ++i) {
+        const int j = lane + 64 * i;
+        if (j < total) dst[j] = tr.q[i];
+    }
+}
+
+// canonical u between tile row `lane` and the fixed row xs (reference column order: xs[0] = time, xs[1 + e])
+__device__ __forceinline__ float hm_tile_u(const float* tile, int RS, int d, const float* xs, int sign_mode, int lane)
+{
+    const float* r = tile + lane * RS;
+    const float S = hm::torch_order_sum([&](int e) { return r[hm_img_off(e)] * xs[1 + e]; }, d);
+    const float t = r[RS - 4] * xs[0];
+    const float m = t - S;
+    return sign_mode ? m : -m;
+}

@@ -259,6 +259,15 @@ class MergeEngine:
         nb = (float(b[1:2].view(np.float32)[0]), int(b[2]), int(b[3])) if b[0] == 1 else None
         return self._unpack(int(steps)), int(done.value), nb
 
+    def debug_time_loops(self, on: bool) -> None:
+        """Measurement aid: event pairs around every scan of the following ``std_merge_steps`` batches."""
+        self._chk(self._L.hm_debug_time_loops(self._h, 1 if on else 0))
+
+    def last_loop_timing(self) -> dict:
+        b, s, k = C.c_float(0), C.c_float(0), C.c_int64(0)
+        self._L.hm_last_loop_timing(self._h, C.byref(b), C.byref(s), C.byref(k))
+        return {"batch_ms": float(b.value), "scan_ms": float(s.value), "steps": int(k.value)}
+
     # -- enhanced tokenizer (config 5) ----------------------------------------------------------------
     def coherence_distances(self, I, J, W, S, c: float) -> np.ndarray:
         """distance(exp_map(x_i, w * log_map(x_i, x_j)), x_s) for every candidate t and its samples S[t, :]

@@ -46,7 +46,7 @@ import torch
 from tqdm import tqdm
 
 from .fast_hyperbolic_merge import CandidateList, FastHyperbolicTokenizer, MergeCandidate
-from .hyperbolic_merge import TQDM_OFF
+from .hyperbolic_merge import TQDM_OFF, _loop_without_cyclic_gc
 
 try:  # the reference consults WordNet when nltk is installed (:39-47); it is optional here too
     import nltk  # noqa: F401
@@ -638,6 +638,7 @@ class EnhancedFastHyperbolicTokenizer(FastHyperbolicTokenizer):
     # ------------------------------------------------------------------------------------------
     # the loop
     # ------------------------------------------------------------------------------------------
+    @_loop_without_cyclic_gc
     def optimize_merges(self, steps: int = 10000, log_every: int = 1000, corpus_sample: Optional[List[str]] = None,
                         adaptive_threshold: bool = True,
                         phase_transition_steps: Optional[Dict[int, int]] = None) -> None:

@@ -23,7 +23,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .hyperbolic_merge import TQDM_OFF, HyperbolicTokenizer
+from .hyperbolic_merge import TQDM_OFF, HyperbolicTokenizer, _loop_without_cyclic_gc
 
 FAISS_AVAILABLE = False     # replaced entirely by the exact GPU search
 
@@ -399,6 +399,7 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         dists = [float(v) for v in self._get_engine().pair_distance(ii, jj, self.curvature)]
         return {"min": min(dists), "max": max(dists), "mean": np.mean(dists), "std": np.std(dists)}
 
+    @_loop_without_cyclic_gc
     def optimize_merges(self, steps: int = 10000, log_every: int = 1000, text_sample: Optional[List[str]] = None,
                         adaptive_threshold: bool = True) -> None:
         """Reference ``:467-576`` step for step (threshold rewrites, statistics calls and their RNG

@@ -29,6 +29,9 @@ search and never used: ``FAISS_AVAILABLE`` is always False here.
 """
 from __future__ import annotations
 
+import contextlib
+import functools
+import gc
 import json
 import logging
 import os
@@ -77,6 +80,29 @@ class _MergePlan:
     def matches(self, i: int, j: int, row: int) -> bool:
         p = self.pos
         return p < len(self.i) and self.i[p] == i and self.j[p] == j and self.row0 + p == row
+
+
+@contextlib.contextmanager
+def _cyclic_gc_paused():
+    """The merge loops create strings, tuples of strings and numbers -- nothing that can form a reference cycle --
+    but their allocations drive the interpreter's generational collector, and one full sweep of a heap that holds
+    torch (about half a million tracked objects after ``import torch``) costs tens of milliseconds: more than a
+    hundred loop steps.  The collector is paused for the duration of a loop and restored afterwards."""
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
+def _loop_without_cyclic_gc(fn):
+    @functools.wraps(fn)
+    def run(*args, **kwargs):
+        with _cyclic_gc_paused():
+            return fn(*args, **kwargs)
+    return run
 
 
 class HyperbolicTokenizer:
@@ -163,8 +189,8 @@ class HyperbolicTokenizer:
         """Force the engine to re-read the table (after editing ``embeddings.data`` by hand)."""
         self._engine_key = None
 
-    def _search_threshold(self) -> float:
-        n = self.current_vocab_size
+    def _search_threshold(self, n: Optional[int] = None) -> float:
+        n = self.current_vocab_size if n is None else n
         return threshold_for_fp32_compare(self.merge_threshold) if n > 100 \
             else threshold_for_double_compare(self.merge_threshold)
 
@@ -334,6 +360,7 @@ class HyperbolicTokenizer:
                     exhausted = True
         return merged, exhausted
 
+    @_loop_without_cyclic_gc
     def optimize_merges(self, steps: int = 10000, log_every: int = 1000, parallel_eval: bool = True,
                         sample_ratio: float = 1.0) -> None:
         """Greedy merge loop (reference ``:357-412``).  ``parallel_eval`` and ``sample_ratio`` never

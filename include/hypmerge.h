@@ -175,6 +175,12 @@ int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev, int64_t l
 int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_dev, int64_t ld, int64_t steps, uint32_t* best_io,
                         uint32_t* rec_out, int64_t* done, void* stream);
 
+/* Measurement aid: with on != 0, hm_std_merge_steps records a HIP event pair around every scan launch of a batch (all of
+ * them enter hm_scan_totals) and around the whole batch; hm_last_loop_timing returns the last batch's wall time on the
+ * device, the sum of its scan launches and its step count (0 when the batch stopped early). */
+int hm_debug_time_loops(hm_engine* e, int on);
+int hm_last_loop_timing(const hm_engine* e, float* batch_ms, float* scan_ms, int64_t* steps);
+
 /* ---- enhanced tokenizer (BASELINE config 5) ---------------------------------------------------------------
  * Semantic-coherence distances: for candidate t the simulated merged embedding
  * m = exp_map(x_I[t], W[t] * log_map(x_I[t], x_J[t])) -- NOT projected -- and out_dev[t * ns + s] =
