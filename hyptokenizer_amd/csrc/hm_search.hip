@@ -433,7 +433,9 @@ static int hm_select_sorted(hm_engine* e, uint4* src, uint4* other, uint32_t m, 
     uint4* cur = src;
     uint4* spare = other;
     uint32_t mcur = m;
-    const uint32_t rank_limit = std::min<uint32_t>(HM_RANK_LIMIT, std::max<uint32_t>(2u * k, 8192u));
+    // up to HM_RANK_LIMIT entries are sorted outright: two more kernels cost less than the two host round trips of a
+    // narrowing level (measured on the refresh of the fast tokenizer: ~100 us against ~30 us)
+    const uint32_t rank_limit = HM_RANK_LIMIT;
     if (mcur > rank_limit) {
         // radix narrowing on the 96-bit key, 12/12/8-bit digits per word
         Prefix pf; memset(&pf, 0, sizeof(pf));
