@@ -41,5 +41,17 @@ if "SQ_BUSY_CU_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
     der["cu_busy_fraction"] = c["SQ_BUSY_CU_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 32)
 if "SQ_LDS_BANK_CONFLICT" in c and "SQ_LDS_IDX_ACTIVE" in c:
     der["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+# launch duration under the counter passes (kernel trace of every pass, first dispatch of each dropped) and, from the
+# pass that holds GRBM_GUI_ACTIVE (a sum over the 8 XCDs), the shader clock the kernel actually ran at
+durs = []
+for d in dirs:
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        durs += [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[1:]]
+if durs:
+    der["avg_launch_us_under_pmc"] = sum(durs) / len(durs)
+    if c.get("GRBM_GUI_ACTIVE"):
+        der["shader_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / der["avg_launch_us_under_pmc"] / 1e3
 json.dump({"kernel_filter": kern, "counters": c, "derived": der}, open(out, "w"), indent=1)
 print(json.dumps(der, indent=1))
