@@ -44,6 +44,28 @@ def pairs_in_rows(n: int, r0: int, r1: int) -> int:
     return cnt * (n - 1) - (r0 + r1 - 1) * cnt // 2
 
 
+def merge_topk_lists_device(allv: torch.Tensor, k: int):
+    """k smallest of the ranks' gathered lists by (distance bits, i, j), on the device.  ``allv``: int32
+    [world, k + 1, 3]; row 0 of a rank = (entries, count low 31 bits, count high bits), rows 1.. = (bits(d), i, j).
+    Three stable sorts (j, then i, then the distance bits -- non-negative floats order like their int32 views); only
+    the k winners and the headers travel to the host."""
+    world = allv.shape[0]
+    hdr = allv[:, 0, :].cpu().numpy()
+    total = int(sum(int(h[1]) + (int(h[2]) << 31) for h in hdr))
+    ent = allv[:, 1:, :]
+    valid = torch.arange(k, device=allv.device)[None, :] < allv[:, 0, 0:1]
+    du = torch.where(valid, ent[:, :, 0], torch.full_like(ent[:, :, 0], 0x7FFFFFFF)).reshape(-1)
+    ii, jj = ent[:, :, 1].reshape(-1), ent[:, :, 2].reshape(-1)
+    order = torch.sort(jj, stable=True).indices
+    order = order[torch.sort(ii[order], stable=True).indices]
+    order = order[torch.sort(du[order], stable=True).indices]
+    keep = order[:min(k, int(hdr[:, 0].sum()))]
+    win = torch.stack((du[keep], ii[keep], jj[keep]), dim=1).cpu().numpy()
+    assert world >= 1
+    return (np.ascontiguousarray(win[:, 0]).view(np.float32), np.ascontiguousarray(win[:, 1]).astype(np.int32),
+            np.ascontiguousarray(win[:, 2]).astype(np.int32), total)
+
+
 class ShardContext:
     """Process-group plumbing for one rank."""
 
@@ -115,6 +137,8 @@ class ShardContext:
         mine = torch.from_numpy(buf).to(self.device)
         out = torch.empty((self.world * (k + 1), 3), dtype=torch.int32, device=self.device)
         dist.all_gather_into_tensor(out, mine, group=self.group)
+        if self.device.type == "cuda":
+            return merge_topk_lists_device(out.view(self.world, k + 1, 3), k)
         allb = out.cpu().numpy().reshape(self.world, k + 1, 3)
         total = 0
         ds, is_, js = [], [], []

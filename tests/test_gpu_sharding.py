@@ -139,3 +139,32 @@ def test_two_ranks_over_rccl_when_two_gpus_are_visible():
     for r in range(world):
         assert results[r]["std_merges"] == ref["std_merges"] and results[r]["fast_merges"] == ref["fast_merges"], r
         assert results[r]["std_rows"] == ref["std_rows"], r
+
+
+@pytest.mark.gpu
+def test_device_merge_of_gathered_topk_lists_matches_lexsort():
+    """The N-rank refresh merges the ranks' ordered lists on the device (sharding.merge_topk_lists_device); with one
+    GPU here the gathered buffer is built by hand: ragged lists, ties in the distance, a rank with nothing."""
+    from hyptokenizer_amd.sharding import merge_topk_lists_device
+    rng = np.random.default_rng(3)
+    world, k = 5, 700
+    buf = np.zeros((world, k + 1, 3), np.int32)
+    lists, total = [], 0
+    for r in range(world):
+        m = [700, 0, 123, 700, 699][r]
+        d = np.sort(rng.choice(np.linspace(0.0, 0.4, 300, dtype=np.float32), size=m))       # many equal distances
+        i = rng.integers(0, 5000, m).astype(np.int32)
+        j = (i + rng.integers(1, 5000, m)).astype(np.int32)
+        cnt = m + int(rng.integers(0, 2 ** 33))
+        buf[r, 0] = (m, cnt & 0x7FFFFFFF, cnt >> 31)
+        buf[r, 1:m + 1, 0] = d.view(np.int32)
+        buf[r, 1:m + 1, 1], buf[r, 1:m + 1, 2] = i, j
+        lists.append((d, i, j))
+        total += cnt
+    du = np.concatenate([x[0].view(np.uint32) for x in lists])
+    ii = np.concatenate([x[1] for x in lists])
+    jj = np.concatenate([x[2] for x in lists])
+    order = np.lexsort((jj, ii, du))[:k]
+    d, i, j, tot = merge_topk_lists_device(torch.from_numpy(buf).cuda(), k)
+    assert tot == total
+    assert np.array_equal(d.view(np.uint32), du[order]) and np.array_equal(i, ii[order]) and np.array_equal(j, jj[order])
