@@ -44,6 +44,11 @@ def _np_ptr(a: np.ndarray) -> C.c_void_p:
     return C.c_void_p(a.ctypes.data)
 
 
+def _f(x) -> float:
+    """Python float of a number or of a (possibly grad-requiring) 0-d tensor such as the enhanced tokenizer's curvature."""
+    return float(x.detach()) if isinstance(x, torch.Tensor) else float(x)
+
+
 class MergeEngine:
     """Handle of one ``hm_engine`` (include/hypmerge.h)."""
 
@@ -111,7 +116,7 @@ class MergeEngine:
     def argmin(self, c: float, thr: float, row_begin: int = 0, row_end: int = -1) -> Optional[Tuple[float, int, int]]:
         """Nearest pair (d, i, j) with d < thr in the reference's order, or None."""
         d, i, j, f = C.c_float(0), C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
-        self._chk(self._L.hm_pairwise_argmin(self._h, float(c), float(thr), int(row_begin), int(row_end),
+        self._chk(self._L.hm_pairwise_argmin(self._h, _f(c), float(thr), int(row_begin), int(row_end),
                                              C.byref(d), C.byref(i), C.byref(j), C.byref(f), self._stream()))
         if not f.value:
             return None
@@ -120,7 +125,7 @@ class MergeEngine:
     def row_argmin(self, row: int, n_partners: int, c: float, thr: float) -> Optional[Tuple[float, int, int]]:
         """Nearest partner of `row` among rows [0, n_partners): (d, i, j) with i < j, or None."""
         d, i, j, f = C.c_float(0), C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
-        self._chk(self._L.hm_row_argmin(self._h, int(row), int(n_partners), float(c), float(thr),
+        self._chk(self._L.hm_row_argmin(self._h, int(row), int(n_partners), _f(c), float(thr),
                                         C.byref(d), C.byref(i), C.byref(j), C.byref(f), self._stream()))
         if not f.value:
             return None
@@ -131,7 +136,7 @@ class MergeEngine:
         tensor `rec` on the current stream (found = 2: buffer overflow, use ``argmin``)."""
         if rec.device != self.device or rec.dtype != torch.int32 or rec.numel() < 4 or not rec.is_contiguous():
             raise ValueError("rec must be a contiguous int32[4] tensor on the engine's device")
-        self._chk(self._L.hm_pairwise_argmin_dev(self._h, float(c), float(thr), int(row_begin), int(row_end),
+        self._chk(self._L.hm_pairwise_argmin_dev(self._h, _f(c), float(thr), int(row_begin), int(row_end),
                                                  _ptr(rec), self._stream()))
 
     def topk(self, c: float, thr: float, k: int, row_begin: int = 0, row_end: int = -1, count: bool = True):
@@ -144,7 +149,7 @@ class MergeEngine:
         j = np.empty(k, np.int32)
         n_out, total = C.c_int64(0), C.c_int64(0)
         fn = self._L.hm_pairwise_topk if count else self._L.hm_pairwise_topk_nocount
-        self._chk(fn(self._h, float(c), float(thr), k, int(row_begin), int(row_end),
+        self._chk(fn(self._h, _f(c), float(thr), k, int(row_begin), int(row_end),
                      _np_ptr(d), _np_ptr(i), _np_ptr(j), C.byref(n_out), C.byref(total), self._stream()))
         m = int(n_out.value)
         return d[:m], i[:m], j[:m], int(total.value)
@@ -152,7 +157,7 @@ class MergeEngine:
     def count_candidates(self, c: float, thr: float, n_limit: int = -1) -> int:
         """Exact number of candidates among the first ``n_limit`` rows (-1: all live rows)."""
         total = C.c_int64(0)
-        self._chk(self._L.hm_pairwise_count(self._h, float(c), float(thr), int(n_limit), C.byref(total), self._stream()))
+        self._chk(self._L.hm_pairwise_count(self._h, _f(c), float(thr), int(n_limit), C.byref(total), self._stream()))
         return int(total.value)
 
     def set_prefilter(self, prefilter: str) -> None:
@@ -160,20 +165,20 @@ class MergeEngine:
 
     def debug_force_cut(self, cut_bits: int, k: int, c: float) -> None:
         """test hook (include/hypmerge.h hm_debug_force_cut)"""
-        self._chk(self._L.hm_debug_force_cut(self._h, int(cut_bits), int(k), float(c)))
+        self._chk(self._L.hm_debug_force_cut(self._h, int(cut_bits), int(k), _f(c)))
 
     def candidates(self, c: float, thr: float, row_begin: int = 0, row_end: int = -1, cap: int = 1 << 24):
         """All candidates in row-major order: (i, j, d, total)."""
         total = C.c_int64(0)
         # first call sizes the arrays
-        self._chk(self._L.hm_pairwise_candidates(self._h, float(c), float(thr), int(row_begin), int(row_end), 0,
+        self._chk(self._L.hm_pairwise_candidates(self._h, _f(c), float(thr), int(row_begin), int(row_end), 0,
                                                  None, None, None, C.byref(total), self._stream()))
         m = min(int(total.value), int(cap))
         i = np.empty(m, np.int32)
         j = np.empty(m, np.int32)
         d = np.empty(m, np.float32)
         if m:
-            self._chk(self._L.hm_pairwise_candidates(self._h, float(c), float(thr), int(row_begin), int(row_end), m,
+            self._chk(self._L.hm_pairwise_candidates(self._h, _f(c), float(thr), int(row_begin), int(row_end), m,
                                                      _np_ptr(i), _np_ptr(j), _np_ptr(d), C.byref(total),
                                                      self._stream()))
             order = np.lexsort((j, i))
@@ -189,14 +194,14 @@ class MergeEngine:
     def pair_distance(self, I, J, c: float) -> np.ndarray:
         ti, tj = self._idx(I), self._idx(J)
         out = torch.empty(ti.numel(), dtype=torch.float32, device=self.device)
-        self._chk(self._L.hm_pair_distance(self._h, _ptr(ti), _ptr(tj), ti.numel(), float(c), _ptr(out), self._stream()))
+        self._chk(self._L.hm_pair_distance(self._h, _ptr(ti), _ptr(tj), ti.numel(), _f(c), _ptr(out), self._stream()))
         return out.cpu().numpy()
 
     def midpoint(self, I, J, W, c: float) -> torch.Tensor:
         ti, tj = self._idx(I), self._idx(J)
         tw = torch.as_tensor(np.ascontiguousarray(W, dtype=np.float32), device=self.device)
         out = torch.empty((ti.numel(), self.d1), dtype=torch.float32, device=self.device)
-        self._chk(self._L.hm_midpoint_batch(self._h, _ptr(ti), _ptr(tj), _ptr(tw), ti.numel(), float(c), _ptr(out),
+        self._chk(self._L.hm_midpoint_batch(self._h, _ptr(ti), _ptr(tj), _ptr(tw), ti.numel(), _f(c), _ptr(out),
                                             self._stream()))
         return out
 
@@ -204,7 +209,7 @@ class MergeEngine:
         t = self._check_table(table)
         if not (0 <= new_row < t.shape[0]):
             raise ValueError("new_row outside the table")
-        self._chk(self._L.hm_merge_append(self._h, int(i), int(j), float(w), float(c), _ptr(t), t.stride(0),
+        self._chk(self._L.hm_merge_append(self._h, int(i), int(j), float(w), _f(c), _ptr(t), t.stride(0),
                                           int(new_row), self._stream()))
 
     def merge_append_batch(self, I, J, W, c: float, table: torch.Tensor, first_row: int, independent: bool = False) -> None:
@@ -220,7 +225,7 @@ class MergeEngine:
         for lo in range(0, ii.shape[0], 4096):
             hi = min(lo + 4096, ii.shape[0])
             self._chk(self._L.hm_merge_append_batch_host(self._h, _np_ptr(ii[lo:hi]), _np_ptr(jj[lo:hi]), _np_ptr(ww[lo:hi]), hi - lo,
-                                                         float(c), _ptr(t), t.stride(0), int(first_row) + lo,
+                                                         _f(c), _ptr(t), t.stride(0), int(first_row) + lo,
                                                          1 if independent else 0, self._stream()))
 
     def truncate(self, n_rows: int) -> None:
@@ -240,7 +245,7 @@ class MergeEngine:
         record = (found, d, i, j): found 1 merged, 0 no candidate, 2 overflow at this step, 3 skipped."""
         t = self._check_table(table)
         done = C.c_int64(0)
-        self._chk(self._L.hm_std_merge_steps(self._h, float(c), float(thr), _ptr(t), t.stride(0), int(steps),
+        self._chk(self._L.hm_std_merge_steps(self._h, _f(c), float(thr), _ptr(t), t.stride(0), int(steps),
                                              _np_ptr(self._rec_buf), C.byref(done), self._stream()))
         return self._unpack(int(steps)), int(done.value)
 
@@ -254,7 +259,7 @@ class MergeEngine:
             b[1] = np.float32(best[0]).view(np.uint32)
             b[2], b[3] = best[1], best[2]
         done = C.c_int64(0)
-        self._chk(self._L.hm_incr_merge_steps(self._h, float(c), float(thr), _ptr(t), t.stride(0), int(steps),
+        self._chk(self._L.hm_incr_merge_steps(self._h, _f(c), float(thr), _ptr(t), t.stride(0), int(steps),
                                               _np_ptr(b), _np_ptr(self._rec_buf), C.byref(done), self._stream()))
         nb = (float(b[1:2].view(np.float32)[0]), int(b[2]), int(b[3])) if b[0] == 1 else None
         return self._unpack(int(steps)), int(done.value), nb
@@ -279,7 +284,7 @@ class MergeEngine:
         out = torch.empty(S.shape, dtype=torch.float32, device=self.device)
         if S.size:
             self._chk(self._L.hm_coherence_batch(self._h, _ptr(ti), _ptr(tj), _ptr(tw), _ptr(ts), ti.numel(), S.shape[1],
-                                                 float(c), _ptr(out), self._stream()))
+                                                 _f(c), _ptr(out), self._stream()))
         return out.cpu().numpy()
 
     def project_table(self, table: torch.Tensor, n_rows: int, c: float) -> None:
@@ -288,19 +293,19 @@ class MergeEngine:
         t = self._check_table(table)
         if n_rows > t.shape[0]:
             raise ValueError("n_rows outside the table")
-        self._chk(self._L.hm_project_table(self._h, _ptr(t), t.stride(0), int(n_rows), float(c), self._stream()))
+        self._chk(self._L.hm_project_table(self._h, _ptr(t), t.stride(0), int(n_rows), _f(c), self._stream()))
 
     def rows_pair_distance(self, table: torch.Tensor, A, B, c: float) -> np.ndarray:
         """distance(table[A[t]], table[B[t]]) on ANY rows of the caller's table (not only live image rows)."""
         t = table.detach()
         ia = torch.as_tensor(np.ascontiguousarray(A, dtype=np.int64), device=t.device)
         ib = torch.as_tensor(np.ascontiguousarray(B, dtype=np.int64), device=t.device)
-        out = device_rows_op("distance", t.index_select(0, ia), t.index_select(0, ib), float(c), self.sign_mode)
+        out = device_rows_op("distance", t.index_select(0, ia), t.index_select(0, ib), _f(c), self.sign_mode)
         return out.cpu().numpy()
 
     def row_vs_all(self, row: int, n: int, c: float) -> np.ndarray:
         out = torch.empty(int(n), dtype=torch.float32, device=self.device)
-        self._chk(self._L.hm_row_vs_all(self._h, int(row), int(n), float(c), _ptr(out), self._stream()))
+        self._chk(self._L.hm_row_vs_all(self._h, int(row), int(n), _f(c), _ptr(out), self._stream()))
         return out.cpu().numpy()
 
     def scan_stats(self) -> dict:
@@ -347,7 +352,7 @@ def device_batch_distance(x: torch.Tensor, y: torch.Tensor, c: float, sign_mode:
     out = torch.empty((xx.shape[0], yy.shape[0]), dtype=torch.float32, device=xx.device)
     with torch.cuda.device(xx.device):
         _lib.check(L.hm_batch_distance(_ptr(xx), xx.shape[0], _ptr(yy), yy.shape[0], xx.stride(0) if xx.shape[0] > 1 else xx.shape[1],
-                                       yy.stride(0) if yy.shape[0] > 1 else yy.shape[1], xx.shape[1], float(c), int(sign_mode),
+                                       yy.stride(0) if yy.shape[0] > 1 else yy.shape[1], xx.shape[1], _f(c), int(sign_mode),
                                        _ptr(out), _stream_of(xx)))
     return out
 
@@ -378,7 +383,7 @@ def device_rows_op(op: str, x: torch.Tensor, y: Optional[torch.Tensor], c: float
             if op == "minkowski":
                 _lib.check(L.hm_rows_minkowski(_ptr(xb), _ptr(yb), b, d1, d1, int(sign_mode), _ptr(out), s))
             else:
-                _lib.check(L.hm_rows_distance(_ptr(xb), _ptr(yb), b, d1, d1, float(c), int(sign_mode), _ptr(out), s))
+                _lib.check(L.hm_rows_distance(_ptr(xb), _ptr(yb), b, d1, d1, _f(c), int(sign_mode), _ptr(out), s))
             return out.reshape(shape[:-1])
         out = torch.empty((b, d1), dtype=torch.float32, device=xb.device)
         if op == "log_map":
@@ -386,7 +391,7 @@ def device_rows_op(op: str, x: torch.Tensor, y: Optional[torch.Tensor], c: float
         elif op == "exp_map":
             _lib.check(L.hm_rows_exp_map(_ptr(xb), _ptr(yb), b, d1, d1, _ptr(out), d1, s))
         elif op == "project":
-            _lib.check(L.hm_rows_project(_ptr(xb), b, d1, d1, float(c), _ptr(out), d1, s))
+            _lib.check(L.hm_rows_project(_ptr(xb), b, d1, d1, _f(c), _ptr(out), d1, s))
         else:
             raise ValueError(op)
     return out.reshape(shape)

@@ -282,7 +282,7 @@ class EnhancedFastHyperbolicTokenizer(FastHyperbolicTokenizer):
         if not self.use_frequency_aware or count == 0:
             return np.zeros(count, np.float64)
         samples = self._coherence_samples(count)
-        lens = np.fromiter((len(t) for t in self.vocab), dtype=np.int64, count=len(self.vocab))
+        lens = self._token_lengths()                      # len(vocab[r]), kept as an array and extended as tokens are appended
         li, lj = lens[ii], lens[jj]
         w = (lj / (li + lj)).astype(np.float64)           # weight_j, a Python double in the reference (:316)
         dist = self._get_engine().coherence_distances(ii, jj, w.astype(np.float32), samples, self._c())
