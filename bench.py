@@ -222,6 +222,18 @@ def bandwidth_kernels(device) -> list:
         rec("hm_incr_step_kernel", (n + done_total / 2) * rs_bytes, s,
             "one launch per merge: midpoint + new row vs all rows + fold; wall time of 64-step batches / steps (host sync per batch included)")
     del eng
+    # the same row-vs-all pass on the largest table an engine takes (131 072 rows): at 50 000 rows a launch moves
+    # 21.8 MB, which the whole chip streams in under 3 us -- launch latency and one memory round trip are most of the
+    # 7-8 us measured above; the larger table shows the kernel's streaming rate
+    nb = 131072
+    tb = torch.zeros((nb, d1), device=device)
+    tb[:] = lorentz_table(nb, D, seed=SEED + 1, scale=SCALE).to(device)
+    engb = MergeEngine(nb, d1, "lorentz", device)
+    engb.set_table(tb, nb)
+    ob = torch.empty(nb, device=device)
+    s = timed(lambda: L.hm_row_vs_all(engb._h, nb - 1, nb, C.c_float(CURV), C.c_void_p(ob.data_ptr()), stream), 50)
+    rec("hm_rowvsall_kernel (n = 131072)", nb * (rs_bytes + 4), s, "row n-1 against all rows of the largest table (56.7 MB image)")
+    del engb
     return out
 
 
@@ -272,7 +284,7 @@ def config5_leg(device, steps: int = 24) -> dict:
     return {"workload": f"EnhancedFastHyperbolicTokenizer.optimize_merges V={n5} d={d5} lorentz thr={thr:.4f} ({cnt0} candidates at the "
                         f"first refresh) freq-aware + adaptive curvature (one curvature step + whole-table re-projection inside the run)",
             "merges_per_s": done / el, "ms_per_step": 1e3 * el / max(done, 1), "steps": done,
-            "curvature_after": float(tok.get_curvature()),
+            "curvature_after": float(torch.as_tensor(tok.get_curvature()).detach()),
             "host_randperm_ms": rp * 1e3,
             "note": "per scored candidate the host draws torch.randperm(n)[:50] (reference semantics, enhanced_fast_hyperbolic_merge.py:"
                     "324-325) -- through the library's MT19937 helper (~0.1 ms at n = 100 000; torch.randperm itself: host_randperm_ms); "

@@ -114,7 +114,12 @@ __global__ __launch_bounds__(256) void hm_pairdist_kernel(const float* __restric
     }
 }
 
+#ifndef HM_ROWVS_WAVES
 #define HM_ROWVS_WAVES 2
+#endif
+#ifndef HM_ROWVS_GRID_CAP
+#define HM_ROWVS_GRID_CAP 1024
+#endif
 __global__ __launch_bounds__(64 * HM_ROWVS_WAVES) void hm_rowvsall_kernel(const float* __restrict__ img, int RS, int d, int64_t row, int64_t n,
                                                                           float sqrt_c, int sign_mode, float* __restrict__ out)
 {
@@ -430,7 +435,7 @@ extern "C" int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, floa
             attr_done = true;
         }
         const int64_t nt = (n + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
-        hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)std::min<int64_t>((nt + HM_ROWVS_WAVES - 1) / HM_ROWVS_WAVES, 1024)), dim3(64 * HM_ROWVS_WAVES), lds,
+        hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)std::min<int64_t>((nt + HM_ROWVS_WAVES - 1) / HM_ROWVS_WAVES, HM_ROWVS_GRID_CAP)), dim3(64 * HM_ROWVS_WAVES), lds,
                            (hipStream_t)stream, e->img, e->RS, e->d, row, n, sqrtf(c), e->sign_mode, d_out_dev);
     }
     HM_HIP(hipGetLastError());
