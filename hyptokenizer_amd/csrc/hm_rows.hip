@@ -94,7 +94,7 @@ int hm_build_rows(hm_engine* e, const float* X, int64_t ld, int64_t r0, int64_t 
 // ------------------------------------------------------------------------------------------------
 // gathered / one-vs-all distances on the image (half-wave per output, coalesced row reads)
 // ------------------------------------------------------------------------------------------------
-// (each half-wave takes 32 consecutive outputs per round: hm_halfwave_gather32)
+// (each half-wave takes HM_GATHER consecutive outputs per round: hm_halfwave_gather)
 __global__ __launch_bounds__(256) void hm_pairdist_kernel(const float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
                                                           const int32_t* __restrict__ J, int64_t b, float sqrt_c, int sign_mode,
                                                           float* __restrict__ out)

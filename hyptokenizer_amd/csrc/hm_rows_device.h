@@ -26,7 +26,7 @@ __device__ __forceinline__ void hm_wave_stage_rows(const float* img, int RS, int
 }
 
 // One wave: ms.so[0..d] = exp_map(x, w * log_map(x, y)), projected onto the hyperboloid when `project`.
-// Same operations in the same order as the one-lane form (hm_midpoint_core of round 1 / oracle hmo_midpoint):
+// Same operations in the same order as the one-lane form (oracle hmo_midpoint):
 // element-wise steps spread over the lanes, the two torch-order reductions by hm_halfwave_sum (both half-waves
 // compute them redundantly), the scalar transcendental steps on every lane (uniform).  Returns the squared
 // spatial norm of the result (fmaf chain; only meaningful when `project`).

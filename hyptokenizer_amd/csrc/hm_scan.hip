@@ -731,7 +731,7 @@ bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t r
     // diagonal advance per row block in tiles (rounded down: the kernel clamps to the exact diagonal)
     const int tiles_per_rb = std::max(1, block_rows / cols);
     // column tiles per block: amortise the stationary-row load, but keep enough blocks in flight.
-    // (the knob is in 64-column units, as in round 1)
+    // (the knob is in 64-column units)
     int ch = (a.bf16 ? e->chunk_bf16 : e->chunk_f32) * 64 / cols;
     if (ch < 1) ch = 1;
     while (ch > 4 && (int64_t)nrb * ((a.nct + ch - 1) / ch) < 1024) ch >>= 1;

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
 
     // ---- exact distance of this block's entries, lexicographic min of (d bits, i, j) with d < thr ----
     uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
-    // a half-wave takes 32 consecutive entries per round (hm_halfwave_gather32): lane t finishes entry t
+    // a half-wave takes HM_GATHER consecutive entries per round (hm_halfwave_gather): lane t finishes entry t
     const uint32_t hw = (blockIdx.x * HM_TAIL_THREADS + threadIdx.x) >> 5;          // half-wave id
     const uint32_t stride = active * (HM_TAIL_THREADS >> 5) * HM_GATHER;
     const int t32 = lane & 31;

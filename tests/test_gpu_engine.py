@@ -533,3 +533,29 @@ def test_golden_edge_rows_on_the_hip_engine(oracle, golden_dir, mode):
         assert best is not None and (best[1], best[2]) == order[0]
     else:
         assert best is None
+
+
+def test_loop_timing_mode_changes_nothing_but_the_statistics(oracle):
+    """hm_debug_time_loops (bench.py's instrumented batch): same records as the plain batch; the timing of a complete
+    batch is consistent (scans inside the batch, every launch counted)."""
+    from hyptokenizer_amd.engine import MergeEngine
+    n, d = 3000, 40
+    X = lorentz_table(n, d, seed=21, scale=0.05)
+    runs = []
+    for timed in (False, True):
+        table = torch.zeros((n + 64, d + 1), device="cuda")
+        table[:n] = X.cuda()
+        eng = MergeEngine(n + 64, d + 1, "lorentz")
+        eng.set_table(table, n)
+        eng.set_token_lengths(np.ones(n, np.int32))
+        eng.debug_time_loops(timed)
+        eng.scan_totals(reset=True)
+        recs, done = eng.std_merge_steps(1.0, 0.4, table, 20)
+        runs.append((recs, done, table[n:n + 20].cpu()))
+        if timed:
+            t = eng.last_loop_timing()
+            assert t["steps"] == 20 and 0.0 < t["scan_ms"] < t["batch_ms"]
+            assert eng.scan_totals()["launches"] == 20
+            eng.debug_time_loops(False)
+    assert runs[0][1] == runs[1][1] == 20 and runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][2].view(torch.int32), runs[1][2].view(torch.int32))
