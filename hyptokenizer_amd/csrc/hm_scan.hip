@@ -73,6 +73,9 @@ __device__ __forceinline__ void hm_dma_run(const char* src, uint32_t dst)
     }
 }
 
+#ifndef HM_SCAN_DEEP_PREFETCH
+#define HM_SCAN_DEEP_PREFETCH 1
+#endif
 template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int SUB>
 __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
 {
@@ -178,6 +181,14 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     // ---- per-group pieces ----
     f32x16 acc[PIPE ? 2 : 1][TM];                   // two accumulator sets (see the header) where they fit
     uint4 bpre16 = make_uint4(0, 0, 0, 0);          // first B fragment of the NEXT group, requested by the previous one
+    // bf16 form with two accumulator sets: ALL k-step fragments of a column group are in registers before its MFMAs
+    // start -- requested while the previous group of the tile computes (two register sets, alternating like the
+    // accumulators).  With the fragments requested one k-step ahead, hipcc issued the LDS reads in pairs right
+    // before their first use and the matrix pipe drained while they were in flight (ISA: ds_read x2, s_waitcnt,
+    // 2 MFMA, s_waitcnt, 2 MFMA, ds_read x2, ...).
+    constexpr bool DEEP = (BF != 0) && PIPE && HM_SCAN_DEEP_PREFETCH;
+    // (the one-set kernels -- 128-row waves -- have no registers left for a second fragment set: 60 spills when tried)
+    uint4 bfr[2][DEEP ? NP : 1];
     float2 bpre = make_float2(0.f, 0.f);
 
     // all k-steps of column group `sub` of ring slot `buf` into acc[set].  `fresh`: the first fragment was not
@@ -255,6 +266,57 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             bpre = bn;
         }
         if constexpr (RED) ext = SIGN ? -ext : ext;
+    };
+
+    // The hot form of the bf16 kernel (both groups of a pass run and a finished group is pending): all k-step fragments
+    // of the group are in bfr[set] before its MFMAs start -- requested by the previous group (`fresh` = false) -- and
+    // the next group's go out to bfr[set ^ 1] first thing (`prefetch`), so the LDS latency is paid behind fourteen
+    // MFMAs instead of in front of every second pair.  The other set's bound-test reduction rides along as in mma_group.
+    auto mma_group_deep = [&](auto set_c, int buf, int sub, bool fresh, bool prefetch, float& ext) {
+        constexpr int set = decltype(set_c)::value;
+        constexpr int QN = 16 * TM;
+        if constexpr (DEEP) {
+            const char* bt = smem + buf * TILE_LDS + (sub * 32 + r) * RB16 + 16 * h;
+            if (fresh) {
+#pragma unroll
+                for (int g = 0; g < NP; ++g) bfr[set][g] = *reinterpret_cast<const uint4*>(bt + 32 * g);
+            }
+            ext = acc[set ^ 1][0][0];
+            auto kstep = [&](int g) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    if (g == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
+                                                                              __builtin_bit_cast(bf16x8, bfr[set][g]), z, 0, 0, 0);
+                    } else {
+                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
+                                                                              __builtin_bit_cast(bf16x8, bfr[set][g]), acc[set][tm], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = (g * QN) / NP; q < ((g + 1) * QN) / NP; ++q) {
+                    const float v = acc[set ^ 1][q / 16][q % 16];
+                    ext = SIGN ? __builtin_fmaxf(ext, v) : __builtin_fminf(ext, v);
+                }
+            };
+            // the first k-step goes out before the next group's requests: LDS data returns in order, and a wait placed
+            // behind fresh requests would hold the first MFMA until the first of THEM is back
+            kstep(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // unconditional (behind the last group of a tile the addresses fall into the next slot or the slack behind
+            // the ring and the data is never used): a branch here makes hipcc count the waits of the MFMAs below for
+            // the path WITHOUT the requests, which in the path with them means waiting for the requests themselves
+            (void)prefetch;
+#pragma unroll
+            for (int g = 0; g < NP; ++g) bfr[set ^ 1][g] = *reinterpret_cast<const uint4*>(bt + 32 * RB16 + 32 * g);
+            __builtin_amdgcn_sched_barrier(0);      // the requests stay in front of the remaining MFMAs
+#pragma unroll
+            for (int g = 1; g < NP; ++g) kstep(g);
+            ext = SIGN ? -ext : ext;
+        }
     };
 
     // the lane's most promising u of accumulator set `set` (acc = -M: u = acc under the reference sign, -acc under lorentz)
@@ -453,6 +515,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     __syncthreads();
 
     bool pend = false;               // a finished group waits in the other accumulator set for its bound test
+    bool deep_valid = false;         // bfr[0] holds the fragments of the group about to run (requested by its predecessor)
     int pend_j0s = 0;
     int buf = 0;                     // ring slot of tile t
 
@@ -492,6 +555,21 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             // two groups per pass, the accumulator sets alternating (a rolled loop: two code sites for the slow path)
 #pragma unroll 1
             for (int sp = 0; sp < SUB / 2; ++sp) {
+                if constexpr (DEEP) {
+                    const int ja = j0 + 2 * sp * 32, jb = ja + 32;
+                    if (wave_active && (ja + 31 > i0w) && pend) {     // both groups of the pass run (jb > ja) and one is pending
+                        float ea = 0.0f, eb = 0.0f;
+                        mma_group_deep(std::integral_constant<int, 0>{}, buf, 2 * sp, !deep_valid, true, ea);
+                        finish_group(std::integral_constant<int, 1>{}, ea, pend_j0s);
+                        const bool more = 2 * sp + 2 < SUB;
+                        mma_group_deep(std::integral_constant<int, 1>{}, buf, 2 * sp + 1, false, more, eb);
+                        finish_group(std::integral_constant<int, 0>{}, eb, ja);
+                        pend_j0s = jb;
+                        deep_valid = more;                            // bfr[0] holds the fragments of the tile's next group
+                        continue;
+                    }
+                    deep_valid = false;
+                }
                 {
                     const int sub = 2 * sp;
                     const int j0s = j0 + sub * 32;
