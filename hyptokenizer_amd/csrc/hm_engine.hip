@@ -128,7 +128,7 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     else if (const char* t2 = getenv("HM_TUNE_TM4_ROWS")) { const long v = atol(t2); if (v >= 0) e->big_min_rows = v; }   // round-1 name
     if (const char* t = getenv("HM_TUNE_INCR_TOPK")) e->incremental_topk = atoi(t) != 0;
     if (const char* t = getenv("HM_TUNE_PERSIST")) { const int v = atoi(t); if (v >= 0 && v <= 9) e->persist = v; }
-    if (const char* t = getenv("HM_TUNE_SHAPE")) { const int v = atoi(t); if (v >= 0 && v <= 3) e->force_shape = v; }
+    if (const char* t = getenv("HM_TUNE_SHAPE")) { const int v = atoi(t); if (v >= 0 && v <= 4) e->force_shape = v; }
     if (const char* t = getenv("HM_TUNE_TAIL_DIV")) { const int v = atoi(t); if (v >= 1 && v <= 16) e->tail_div = v; }
     // emission buffers: every pair of the largest table when that is small, 2^24 entries (256 MiB) at most
     {

@@ -73,6 +73,9 @@ __device__ __forceinline__ void hm_dma_run(const char* src, uint32_t dst)
     }
 }
 
+#ifndef HM_SCAN_PIPE_MAX_TM
+#define HM_SCAN_PIPE_MAX_TM 2
+#endif
 #ifndef HM_SCAN_DEEP_PREFETCH
 #define HM_SCAN_DEEP_PREFETCH 1
 #endif
@@ -80,7 +83,7 @@ template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int SUB>
 __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
 {
     static_assert(SUB % 2 == 0, "the two accumulator sets alternate between column groups: an even number per tile");
-    constexpr bool PIPE = (TM <= 2);               // two accumulator sets fit the registers (128 stationary rows per wave: one set)
+    constexpr bool PIPE = (TM <= HM_SCAN_PIPE_MAX_TM);   // two accumulator sets fit the registers (128 stationary rows per wave: one set)
     constexpr int COLS = 32 * SUB;                 // partner rows per streamed tile
     constexpr int RS = hm_row_floats(NG);          // fp32 image: floats per row
     constexpr int RB16 = 32 * NG + 16;             // bf16 image: bytes per row (NG x 16 bf16 + [x0 fp32, pad])
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     // accumulators).  With the fragments requested one k-step ahead, hipcc issued the LDS reads in pairs right
     // before their first use and the matrix pipe drained while they were in flight (ISA: ds_read x2, s_waitcnt,
     // 2 MFMA, s_waitcnt, 2 MFMA, ds_read x2, ...).
-    constexpr bool DEEP = (BF != 0) && PIPE && HM_SCAN_DEEP_PREFETCH;
+    constexpr bool DEEP = (BF != 0) && PIPE && (TM <= 2) && HM_SCAN_DEEP_PREFETCH;
     // (the one-set kernels -- 128-row waves -- have no registers left for a second fragment set: 60 spills when tried)
     uint4 bfr[2][DEEP ? NP : 1];
     float2 bpre = make_float2(0.f, 0.f);
@@ -732,6 +735,7 @@ hipError_t hm_launch_scan(hm_engine* e, int mode, const ScanArgs& a, dim3 grid, 
 #if HM_SCAN_ALL_SHAPES
     if (a.bf16 && a.shape == 2) { HM_BF16_CASES(2, 8) }
     if (a.bf16 && a.shape == 3) { HM_BF16_CASES(4, 8) }
+    if (a.bf16 && a.shape == 4) { HM_BF16_CASES(3, 4) }
 #endif
     if (a.bf16) {
         if (e->KS == 8) {
@@ -783,7 +787,7 @@ bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t r
     // (KS = 8 would not fit the registers of the 128-row waves)
     a.shape = (a.bf16 && e->KS <= 7 && hm_pairs_in_range(n, row_begin, row_end) >= e->big_min_rows * (e->big_min_rows - 1) / 2) ? 1 : 0;
     if (a.bf16 && e->KS <= 7 && e->force_shape >= 0) a.shape = e->force_shape;
-    static const int kShapeRows[4] = {256, 512, 512, 1024};
+    static const int kShapeRows[5] = {256, 512, 512, 1024, 384};
     const int block_rows = a.bf16 ? kShapeRows[a.shape] : 256;
     const int cols = 32 * (a.bf16 ? HM_SUB_BF16 : HM_SUB_F32);     // partner rows per streamed tile
     a.n = (int)n;
