@@ -11,7 +11,7 @@ Two oracle modes:
               ``embedding.lorentz_model.minkowski_dot`` negated (fixes distance/log_map) and
               ``batch_distance`` invoked as ``orig(x, -y, c)`` (it inlines its own dot product).
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [reference|lorentz|all] [all|g5|g6]
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [reference|lorentz|all] [all|g5|g6|g7]
 """
 from __future__ import annotations
 
@@ -529,6 +529,60 @@ def g6_tokenize(mode: str) -> None:
         json.dump(out, f, ensure_ascii=False)
 
 
+# ---------------------------------------------------------------------------------------------
+# G7: directories written by the reference's own save() (hyperbolic_merge.py:473-499; enhanced...:1211-1298),
+# kept as files, plus what the reference's own load() makes of them -- the build's load() must read them
+# ---------------------------------------------------------------------------------------------
+def g7_saved_dirs(mode: str) -> None:
+    import shutil
+    EM = _enhanced_module()
+    root = os.path.join(HERE, f"g7_saved_{mode}")
+    shutil.rmtree(root, ignore_errors=True)
+    os.makedirs(root)
+    n, d = 40, 5
+    X = lorentz_table(n, d, seed=7, scale=0.05)
+    thr = 0.1 if mode == "reference" else 0.35
+    summary = {}
+
+    def describe(tok):
+        k = tok.current_vocab_size
+        return {"vocab": list(tok.vocab), "merge_history": [list(m) for m in tok.merge_history], "current_vocab_size": int(k),
+                "max_vocab_size": int(tok.max_vocab_size), "curvature": float(tok.curvature), "merge_threshold": float(tok.merge_threshold),
+                "embedding_bits": tok.embeddings.data[:k].detach().numpy().view(np.uint32).tolist(),
+                "tokenize": [tok.tokenize(t) for t in ("".join(tok.vocab[:6]), tok.vocab[-1] + tok.vocab[0], "")],
+                "encode": [tok.encode(t) for t in ("".join(tok.vocab[:6]), tok.vocab[-1] + "z")]}
+
+    seed_all(42)
+    std = _mk_tok(HM.HyperbolicTokenizer, X, thr, max_vocab_size=n + 24)
+    std.optimize_merges(steps=6, log_every=10 ** 9)
+    std.save(os.path.join(root, "std"))
+    summary["std"] = describe(HM.HyperbolicTokenizer.load(os.path.join(root, "std"), device=torch.device("cpu")))
+    seed_all(42)
+    fast = _mk_tok(FM.FastHyperbolicTokenizer, X, thr, max_vocab_size=n + 24)
+    fast.optimize_merges(steps=8, log_every=10 ** 9, adaptive_threshold=False)
+    fast.save(os.path.join(root, "fast"))
+    summary["fast"] = describe(FM.FastHyperbolicTokenizer.load(os.path.join(root, "fast"), device=torch.device("cpu")))
+    seed_all(42)
+    enh = _mk_enh(EM, X, thr, dict(use_frequency_aware=True, use_hierarchical=False, use_adaptive_curvature=False,
+                                   use_compression_aware=False), max_vocab_size=n + 24)
+    enh.optimize_merges(steps=5, log_every=10 ** 9, adaptive_threshold=False)
+    enh.save(os.path.join(root, "enhanced"))
+    # The reference's enhanced save() writes the WHOLE pre-allocated table (max_vocab_size rows) and its load() hands
+    # that to a constructor that expects len(vocab) rows: it raises on its own file whenever the table is not full.
+    # The expectation is therefore taken from the object that was saved.
+    try:
+        EM.EnhancedFastHyperbolicTokenizer.load(os.path.join(root, "enhanced"), device=torch.device("cpu"))
+        summary["enhanced_reference_load"] = "ok"
+    except Exception as exc:
+        summary["enhanced_reference_load"] = f"raises {type(exc).__name__}"
+    summary["enhanced"] = describe(enh)
+    summary["enhanced"]["pair_frequencies"] = sorted([[a, b, int(c)] for (a, b), c in enh.pair_frequencies.items()])[:50]
+    summary["enhanced"]["n_pair_frequencies"] = len(enh.pair_frequencies)
+    summary["files"] = {k: sorted(os.listdir(os.path.join(root, k))) for k in ("std", "fast", "enhanced")}
+    with open(os.path.join(root, "expected.json"), "w") as f:
+        json.dump(summary, f, ensure_ascii=False)
+
+
 def main() -> None:
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     only = sys.argv[2] if len(sys.argv) > 2 else "all"      # e.g. "g5": regenerate one family
@@ -542,6 +596,10 @@ def main() -> None:
         if only == "g6":
             g6_tokenize(mode)
             print(f"[{mode}] g6 done", flush=True)
+            continue
+        if only == "g7":
+            g7_saved_dirs(mode)
+            print(f"[{mode}] g7 done", flush=True)
             continue
         g1_primitives(mode)
         print(f"[{mode}] g1 done", flush=True)
