@@ -176,6 +176,7 @@ __global__ __launch_bounds__(64 * HM_INCR_WAVES) void hm_incr_step_kernel(const 
 {
     extern __shared__ __align__(16) float tiles[];
     __shared__ MidScratch ms;
+    __shared__ __align__(16) float ximg[HM_MAX_D1 + 4];          // the merged row in image layout (what the tiles are compared with)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* tile = tiles + wv * HM_TILE_ROWS * a.RS;
     // the first tile of partner rows does not depend on which pair is merged: its loads are in flight during the fold
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(64 * HM_INCR_WAVES) void hm_incr_step_kernel(const 
                 loop->steps_done += 1u;
             }
         }
+        hm_tile_fixed_row(ms.so, a.RS, a.d, ximg, lane);
     }
     __syncthreads();
     // ---- nearest partner of the new row among rows [0, new_row): lane l of a wave takes row l of the wave's tile ----
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(64 * HM_INCR_WAVES) void hm_incr_step_kernel(const 
         hm_wave_lds_sync();
         const int64_t nxt = tl + (int64_t)gridDim.x * HM_INCR_WAVES;
         if (nxt < nt) hm_tile_load(a.img, a.RS, nxt * HM_TILE_ROWS, a.new_row, tr, lane);
-        const float u = hm_tile_u(tile, a.RS, a.d, ms.so, a.sign_mode, lane);
+        const float u = hm_tile_u(tile, a.RS, a.d, ximg, a.sign_mode, lane);
         const int64_t i = tl * HM_TILE_ROWS + lane;
         const float dd = hm::dist_from_u(u, a.sqrt_c);
         if (i < a.new_row && dd < a.thr) {

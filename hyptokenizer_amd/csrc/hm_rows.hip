@@ -124,14 +124,14 @@ __global__ __launch_bounds__(64 * HM_ROWVS_WAVES) void hm_rowvsall_kernel(const 
                                                                           float sqrt_c, int sign_mode, float* __restrict__ out)
 {
     extern __shared__ __align__(16) float lds[];
-    float* xs = lds;                                           // the fixed row, reference column order
+    float* xs = lds;                                           // the fixed row: a copy of its image row (same layout as the tiles)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float* tile = lds + HM_MAX_D1 + 4 + wv * HM_TILE_ROWS * RS;   // (HM_MAX_D1 + 4) % 4 == 0: tiles stay 16-byte aligned
+    float* tile = lds + HM_MAX_D1 + 4 + wv * HM_TILE_ROWS * RS;   // (HM_MAX_D1 + 4) % 4 == 0 and RS <= HM_MAX_D1 + 4: tiles stay 16-byte aligned
     const int64_t nt = (n + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
     int64_t tl = (int64_t)blockIdx.x * HM_ROWVS_WAVES + wv;
     TileRegs tr;
     if (tl < nt) hm_tile_load(img, RS, tl * HM_TILE_ROWS, n, tr, lane);
-    for (int k = threadIdx.x; k <= d; k += blockDim.x) xs[k] = k == 0 ? hm_img_time(img, RS, row) : hm_img_spatial(img, RS, row, k - 1);
+    for (int k = threadIdx.x; k < RS; k += blockDim.x) xs[k] = img[row * RS + k];
     __syncthreads();
     for (; tl < nt; tl += (int64_t)gridDim.x * HM_ROWVS_WAVES) {
         hm_tile_store(tile, RS, tr, lane);

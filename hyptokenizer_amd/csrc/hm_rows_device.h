@@ -140,12 +140,63 @@ __device__ __forceinline__ void hm_tile_store(float* tile, int RS, const TileReg
     }
 }
 
-// canonical u between tile row `lane` and the fixed row xs (reference column order: xs[0] = time, xs[1 + e])
-__device__ __forceinline__ float hm_tile_u(const float* tile, int RS, int d, const float* xs, int sign_mode, int lane)
+// The fixed row in IMAGE layout (RS floats: groups [s0, s2, s1, s3], time group last, zero padding) from the reference
+// column order (xo[0] = time, xo[1 + e]); one wave, no synchronisation inside.
+__device__ __forceinline__ void hm_tile_fixed_row(const float* xo, int RS, int d, float* ximg, int lane)
+{
+    for (int p = lane; p < RS; p += 64) ximg[p] = 0.0f;
+    hm_wave_lds_sync();
+    for (int e = lane; e < d; e += 64) ximg[hm_img_off(e)] = xo[1 + e];
+    if (lane == 0) ximg[RS - 4] = xo[0];
+    hm_wave_lds_sync();
+}
+
+// canonical u between tile row `lane` and the fixed row ximg (image layout, as the tile rows).  Both are read as
+// 16-byte groups (the tile at stride RS: RS / 4 is odd, conflict-free for ds_read_b128; the fixed row is a broadcast);
+// a group holds elements (4g, 4g + 2, 4g + 1, 4g + 3), and element e = 32 i + c feeds chain c of torch's 32 -- so the
+// eight groups of one pass over the chains are fully unrolled with fixed accumulators.  Same sums in the same order as
+// hm::torch_order_sum (rows shorter than 8 take that path).
+__device__ __forceinline__ float hm_tile_u(const float* tile, int RS, int d, const float* ximg, int sign_mode, int lane)
 {
     const float* r = tile + lane * RS;
-    const float S = hm::torch_order_sum([&](int e) { return r[hm_img_off(e)] * xs[1 + e]; }, d);
-    const float t = r[RS - 4] * xs[0];
+    float S;
+    if (d < 8) {
+        S = hm::torch_order_sum([&](int e) { return r[hm_img_off(e)] * ximg[hm_img_off(e)]; }, d);
+    } else {
+        const float4* r4 = reinterpret_cast<const float4*>(r);
+        const float4* x4 = reinterpret_cast<const float4*>(ximg);
+        float acc[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc[c] = 0.0f;
+        const int vec = d >> 3, ilp = vec >> 2;
+        for (int i = 0; i < ilp; ++i) {
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) {
+                const float4 R = r4[8 * i + gg], X = x4[8 * i + gg];
+                acc[4 * gg + 0] = acc[4 * gg + 0] + R.x * X.x;
+                acc[4 * gg + 2] = acc[4 * gg + 2] + R.y * X.y;
+                acc[4 * gg + 1] = acc[4 * gg + 1] + R.z * X.z;
+                acc[4 * gg + 3] = acc[4 * gg + 3] + R.w * X.w;
+            }
+        }
+        // leftover vectors of 8 (two groups each): all into accumulator 0, i.e. chains 0..7
+        for (int q = ilp * 4; q < vec; ++q) {
+            const float4 R0 = r4[2 * q], X0 = x4[2 * q], R1 = r4[2 * q + 1], X1 = x4[2 * q + 1];
+            acc[0] = acc[0] + R0.x * X0.x; acc[2] = acc[2] + R0.y * X0.y; acc[1] = acc[1] + R0.z * X0.z; acc[3] = acc[3] + R0.w * X0.w;
+            acc[4] = acc[4] + R1.x * X1.x; acc[6] = acc[6] + R1.y * X1.y; acc[5] = acc[5] + R1.z * X1.z; acc[7] = acc[7] + R1.w * X1.w;
+        }
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[l] = acc[l] + acc[8 * k + l];
+        // scalar tail: elements 8 vec .. d - 1 in element order, summed from zero
+        float tail = 0.0f;
+        for (int e = vec * 8; e < d; ++e) tail = tail + r[hm_img_off(e)] * ximg[hm_img_off(e)];
+        S = tail;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) S = S + acc[l];
+    }
+    const float t = r[RS - 4] * ximg[RS - 4];
     const float m = t - S;
     return sign_mode ? m : -m;
 }
