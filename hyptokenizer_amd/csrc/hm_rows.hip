@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void hm_pairdist_kernel(const float* __restric
 #define HM_ROWVS_WAVES 2
 #endif
 #ifndef HM_ROWVS_GRID_CAP
-#define HM_ROWVS_GRID_CAP 1024
+#define HM_ROWVS_GRID_CAP 512      // = the blocks resident at once (two per CU): beyond one round a wave takes several tiles, the next one prefetched
 #endif
 __global__ __launch_bounds__(64 * HM_ROWVS_WAVES) void hm_rowvsall_kernel(const float* __restrict__ img, int RS, int d, int64_t row, int64_t n,
                                                                           float sqrt_c, int sign_mode, float* __restrict__ out)
