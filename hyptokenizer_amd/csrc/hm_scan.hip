@@ -354,6 +354,24 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             }
         }
         if (__ballot(ext_u < bound_f) == 0ull) return;
+        if (MODE == HM_MODE_ARGMIN && best_bits == 0x3f7fffffu && p.thr_pos != 0) {
+            // The running best is a pair at distance exactly 0 (the literal sign mode: EVERY pair is one).  A pair that is
+            // certainly at distance 0 too is only emitted when its (i, j) orders before the best's (`low <= best_low`
+            // below); every pair of this group has low >= lowmin.  So when the whole group is certainly-zero and starts
+            // behind the best pair, the slow path would emit nothing: skip it (1.6 ms -> 0.3 ms per tie-flood scan).
+            const uint32_t lowmin = ((uint32_t)i0w << 15) | ((uint32_t)j0s >> 2);
+            if (lowmin > best_low) {
+                float worst = SIGN ? -acc[set][0][0] : acc[set][0][0];          // the LARGEST u of the lane's elements
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float u = SIGN ? -acc[set][tm][e] : acc[set][tm][e];
+                        worst = __builtin_fmaxf(worst, u);
+                    }
+                if (__ballot(!(worst <= zmax_f)) == 0ull) return;                // (NaN counts as not certainly zero)
+            }
+        }
         const bool full = rows_full && (j0s > i0w + WAVE_ROWS - 1) && (j0s + 31 < p.n) && (j0s >= p.col_begin);
         unsigned long long wkey = ~0ull;
         bool wrote = false;
