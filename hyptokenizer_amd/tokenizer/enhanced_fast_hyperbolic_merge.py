@@ -258,7 +258,14 @@ class EnhancedFastHyperbolicTokenizer(FastHyperbolicTokenizer):
         if not self.use_frequency_aware or not self.pair_frequencies:
             return out
         pf = self.pair_frequencies
-        top = max(pf.values())
+        # max over the table (the reference recomputes it for every candidate, :368): once per table state here --
+        # re-derived whenever the dict object or its size changes and at the start of every optimize_merges call
+        key = (id(pf), len(pf))
+        cached = getattr(self, "_freq_top", None)
+        if cached is None or cached[0] != key:
+            cached = (key, max(pf.values()))
+            self._freq_top = cached
+        top = cached[1]
         if not top > 0:
             return out
         counts = np.fromiter((pf.get((self.vocab[a], self.vocab[b]), 0) for a, b in zip(ii.tolist(), jj.tolist())),
@@ -643,6 +650,7 @@ class EnhancedFastHyperbolicTokenizer(FastHyperbolicTokenizer):
                         adaptive_threshold: bool = True,
                         phase_transition_steps: Optional[Dict[int, int]] = None) -> None:
         """Reference ``:1015-1209``."""
+        self._freq_top = None            # counts may have been edited since the last call
         if corpus_sample and self.use_compression_aware:
             self.corpus_sample = corpus_sample
             self.tokenize_cache = {}

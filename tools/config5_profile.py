@@ -16,4 +16,6 @@ pr.enable()
 out = bench.config5_leg(dev)
 pr.disable()
 print({k: v for k, v in out.items() if k != "note"})
-pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+st = pstats.Stats(pr)
+st.sort_stats("cumulative").print_stats("hyptokenizer_amd|randperm|numpy", 30)
+st.sort_stats("tottime").print_stats(18)
