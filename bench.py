@@ -490,7 +490,7 @@ def main() -> None:
         incr = {"merges_per_s": (len(itok.merge_history) - 1) / ti, "steps": isteps - 1,
                 "same_merges_as_full_search": itok.merge_history == tok.merge_history[:len(itok.merge_history)],
                 "note": "HyperbolicTokenizer(incremental=True): one full search, then one launch per merge "
-                        "(midpoint + new row vs all + fold), 64 steps per host call"}
+                        "(midpoint + new row vs all + fold), up to 256 steps per host call"}
         del itok
 
     legs, bw = None, None

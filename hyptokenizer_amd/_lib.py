@@ -22,7 +22,7 @@ HM_OK = 0
 HM_E_ARG, HM_E_CAPACITY, HM_E_STATE, HM_E_NOMEM = -1, -2, -3, -4
 SIGN_REFERENCE, SIGN_LORENTZ = 0, 1
 PREFILTER_AUTO, PREFILTER_F32, PREFILTER_BF16 = 0, 1, 2
-LOOP_MAX_STEPS = 64
+LOOP_MAX_STEPS = 256
 
 #: every symbol include/hypmerge.h declares (tests check that the library exports all of them)
 EXPORTED_SYMBOLS = (

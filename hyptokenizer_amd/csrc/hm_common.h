@@ -53,7 +53,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_TAIL_SOLO 1024u
 #define HM_ROWPASS_BLOCKS 256      // blocks of the one-row-vs-all reduction
 #define HM_PART_SLOTS 256          // partial records (>= HM_TAIL_BLOCKS, HM_ROWPASS_BLOCKS)
-#define HM_LOOP_MAX_STEPS 64
+#define HM_LOOP_MAX_STEPS 256
 #define HM_BATCH_MAX 4096          // merges per hm_merge_append_batch_host call       // steps one device-resident loop call may enqueue
 
 // prefilter forms (hm_engine_create / hm_set_prefilter)

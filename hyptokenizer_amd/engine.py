@@ -241,7 +241,7 @@ class MergeEngine:
         return [(int(f), float(np.uint32(b).view(np.float32)), int(i), int(j)) for f, b, i, j in r.tolist()]
 
     def std_merge_steps(self, c: float, thr: float, table: torch.Tensor, steps: int):
-        """``steps`` (<= 64) iterations of the standard loop on the device -> (records, done);
+        """``steps`` (<= 256) iterations of the standard loop on the device -> (records, done);
         record = (found, d, i, j): found 1 merged, 0 no candidate, 2 overflow at this step, 3 skipped."""
         t = self._check_table(table)
         done = C.c_int64(0)

@@ -42,6 +42,7 @@ import torch
 from tqdm import tqdm
 
 from ..embedding.lorentz_model import batch_distance, distance
+from .._lib import LOOP_MAX_STEPS
 from ..engine import MAX_ROWS, MAX_WIDTH, HypMergeUnavailable, MergeEngine, sign_mode_id
 
 logger = logging.getLogger(__name__)
@@ -327,7 +328,7 @@ class HyperbolicTokenizer:
             room = self.max_vocab_size - self.current_vocab_size
             if room <= 0:
                 raise ValueError(f"Maximum vocabulary size {self.max_vocab_size} reached. Cannot merge more tokens.")
-            k = min(count, 64, room)
+            k = min(count, LOOP_MAX_STEPS, room)
             n = self.current_vocab_size
             if n <= 100:
                 k = min(k, 101 - n)               # the reference compares differently up to 100 tokens (:270-289): one threshold per batch
@@ -370,7 +371,7 @@ class HyperbolicTokenizer:
         if self._device_loop_ok():
             step = 0
             while step < steps:
-                merged, exhausted = self._device_steps(min(64, steps - step))
+                merged, exhausted = self._device_steps(min(LOOP_MAX_STEPS, steps - step))
                 base = self.current_vocab_size - len(merged)
                 for t, (i, j, dist) in enumerate(merged):
                     if (step + 1) % log_every == 0:

@@ -162,7 +162,7 @@ int hm_truncate(hm_engine* e, int64_t n_rows, void* stream);
  * (w = len(tj) / (len(ti) + len(tj)), hyperbolic_merge.py:317-323).  Host array; kept on the device and
  * extended by the loops below (len[new] = len[i] + len[j]). */
 int hm_set_token_lengths(hm_engine* e, const int32_t* lens_host, int64_t n, void* stream);
-/* `steps` (<= 64) iterations of HyperbolicTokenizer.optimize_merges (hyperbolic_merge.py:371-399: full search,
+/* `steps` (<= 256) iterations of HyperbolicTokenizer.optimize_merges (hyperbolic_merge.py:371-399: full search,
  * sort, [0], merge) enqueued back to back -- pair scan + one tail kernel per step, no host round trip -- and read
  * back with one synchronisation.  rec_out[4 * k] = {found, bits(d), i, j} of step k: found 1 = merged (i, j) into
  * row n + k; 0 = no candidate (the loop ends, hyperbolic_merge.py:373-375); 2 = emission overflow at this step (run it
