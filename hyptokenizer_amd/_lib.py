@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "hm_last_scan_stats", "hm_scan_totals", "hm_set_prefilter", "hm_pairwise_topk_nocount", "hm_pairwise_count",
     "hm_merge_append_batch", "hm_truncate", "hm_set_token_lengths", "hm_std_merge_steps", "hm_incr_merge_steps",
     "hm_coherence_batch", "hm_project_table", "hm_debug_force_cut", "hm_randperm_prefix", "hm_merge_append_batch_host",
-    "hm_tokenize_table_capacity", "hm_tokenize_build_table", "hm_tokenize_batch", "hm_debug_time_loops", "hm_last_loop_timing",
+    "hm_tokenize_table_capacity", "hm_tokenize_build_table", "hm_tokenize_batch", "hm_debug_time_loops", "hm_last_loop_timing", "hm_shard_loop_begin", "hm_shard_merge_step", "hm_shard_loop_end",
 )
 
 
@@ -87,6 +87,9 @@ def load() -> C.CDLL:
     L.hm_debug_force_cut.argtypes = [vp, C.c_uint32, i64, f32]
     L.hm_randperm_prefix.argtypes = [vp, pi32, C.POINTER(C.c_uint32), i64, i32, i64, vp]
     L.hm_debug_time_loops.argtypes = [vp, C.c_int]
+    L.hm_shard_loop_begin.argtypes = [vp, vp]
+    L.hm_shard_merge_step.argtypes = [vp, vp, C.c_int, f32, vp, i64, i64, vp]
+    L.hm_shard_loop_end.argtypes = [vp, i64, vp, pi64, vp]
     L.hm_last_loop_timing.argtypes = [vp, pf32, pf32, pi64]
     L.hm_tokenize_table_capacity.restype = i64
     L.hm_tokenize_table_capacity.argtypes = [i64]

@@ -189,6 +189,9 @@ struct hm_engine {
     int64_t prev_k = 0, prev_n = 0;
     float prev_thr = 0.f;
     bool debug_cut = false;               // hm_debug_force_cut: the next top-k starts from last_cut_bits as given
+    // row-sharded device-resident loop (hm_shard_loop_begin .. _end): searches skip themselves once the loop has stopped
+    bool shard_loop = false;
+    int64_t shard_n0 = 0;
     // hm_debug_time_loops: an event pair around EVERY scan of a device-resident batch and around the batch itself
     bool time_loops = false;
     std::vector<hipEvent_t> loop_evs;     // 2 * HM_LOOP_MAX_STEPS + 2, created on first use

@@ -308,3 +308,116 @@ extern "C" int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_de
     e->n = n0 + *done;
     return HM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// row-sharded loop: every rank searches its row range, the ranks' records are all-gathered by the caller (RCCL, on the
+// same stream), and every rank applies the same merge to its replica -- without the host looking at any of it
+// ------------------------------------------------------------------------------------------------
+struct ShardMergeArgs {
+    const ArgminRec* recs;       // `world` records, rank order
+    int world;
+    float* img;
+    unsigned char* img16;
+    int RS, d, KS, sign_mode;
+    float c;
+    float* X;
+    int64_t ld;
+    int64_t new_row;
+    int32_t* len;
+    LoopState* loop;
+    ArgminRec* rec_ring;
+    uint32_t* rmax2_bits;
+};
+
+// one wave: lane r holds rank r's record; global nearest pair = lexicographic min of (d bits, i, j) over the ranks that
+// found one (identical on every rank); an overflow anywhere (found = 2) or no pair at all ends the loop
+__global__ __launch_bounds__(64) void hm_shard_merge_kernel(const ShardMergeArgs a)
+{
+    __shared__ MidScratch ms;
+    const int lane = threadIdx.x;
+    LoopState* loop = a.loop;
+    if (loop->stop != 0u) {
+        if (lane == 0) { ArgminRec r; r.found = 3u; r.dbits = 0; r.i = 0xffffffffu; r.j = 0xffffffffu; *a.rec_ring = r; }
+        return;
+    }
+    ArgminRec mine; mine.found = 0u; mine.dbits = 0xffffffffu; mine.i = 0xffffffffu; mine.j = 0xffffffffu;
+    if (lane < a.world) mine = a.recs[lane];
+    const bool overflow = __ballot(lane < a.world && (mine.found == 2u || mine.found == 3u)) != 0ull;
+    uint32_t b0 = mine.found == 1u ? mine.dbits : 0xffffffffu, b1 = mine.found == 1u ? mine.i : 0xffffffffu,
+             b2 = mine.found == 1u ? mine.j : 0xffffffffu;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o0 = __shfl_xor(b0, off, 64), o1 = __shfl_xor(b1, off, 64), o2 = __shfl_xor(b2, off, 64);
+        if (hm_key_less(o0, o1, o2, b0, b1, b2)) { b0 = o0; b1 = o1; b2 = o2; }
+    }
+    if (overflow || b1 == 0xffffffffu) {
+        if (lane == 0) {
+            ArgminRec r; r.found = overflow ? 2u : 0u; r.dbits = 0; r.i = 0xffffffffu; r.j = 0xffffffffu;
+            *a.rec_ring = r;
+            loop->stop = overflow ? 2u : 1u;
+        }
+        return;
+    }
+    const int32_t li = a.len[b1], lj = a.len[b2];
+    const float w = (float)((double)lj / (double)(li + lj));
+    hm_wave_stage_rows(a.img, a.RS, a.d, b1, b2, ms, lane);
+    const float r2 = hm_wave_midpoint(a.d, w, a.c, a.sign_mode, ms, true, lane);
+    hm_wave_store_row(ms, r2, a.d, a.RS, a.KS, a.X, a.ld, a.img, a.img16, a.new_row, a.rmax2_bits, lane);
+    if (lane == 0) {
+        a.len[a.new_row] = li + lj;
+        ArgminRec r; r.found = 1u; r.dbits = b0; r.i = b1; r.j = b2;
+        *a.rec_ring = r;
+        loop->steps_done += 1u;
+    }
+}
+
+extern "C" int hm_shard_loop_begin(hm_engine* e, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_shard_loop_begin: engine is NULL");
+    if (!e->have_len) return hm_fail(e, HM_E_STATE, "hm_shard_loop_begin: token lengths not set (hm_set_token_lengths)");
+    if (e->shard_loop) return hm_fail(e, HM_E_STATE, "hm_shard_loop_begin: a loop is already open");
+    HM_HIP(hipSetDevice(e->device));
+    HM_HIP(hipMemsetAsync(e->d_loop, 0, sizeof(LoopState), (hipStream_t)stream));
+    e->shard_loop = true;
+    e->shard_n0 = e->n;
+    return HM_OK;
+}
+
+extern "C" int hm_shard_merge_step(hm_engine* e, const uint32_t* recs_dev, int world, float c, float* X_dev, int64_t ld, int64_t step,
+                                   void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_shard_merge_step: engine is NULL");
+    if (!e->shard_loop) return hm_fail(e, HM_E_STATE, "hm_shard_merge_step: no open loop (hm_shard_loop_begin)");
+    if (!recs_dev || world < 1 || world > 64 || !X_dev || ld < e->d1 || step < 0 || step >= HM_LOOP_MAX_STEPS || !(c > 0.0f))
+        return hm_fail(e, HM_E_ARG, "hm_shard_merge_step: bad arguments");
+    if (e->n + 1 > e->max_rows) return hm_fail(e, HM_E_CAPACITY, "hm_shard_merge_step: the table is full");
+    HM_HIP(hipSetDevice(e->device));
+    ShardMergeArgs a;
+    a.recs = reinterpret_cast<const ArgminRec*>(recs_dev); a.world = world;
+    a.img = e->img; a.img16 = e->img16; a.RS = e->RS; a.d = e->d; a.KS = e->KS; a.sign_mode = e->sign_mode;
+    a.c = c; a.X = X_dev; a.ld = ld; a.new_row = e->n; a.len = e->d_len; a.loop = e->d_loop;
+    a.rec_ring = e->d_loop_recs + step; a.rmax2_bits = e->d_rmax2;
+    hipLaunchKernelGGL(hm_shard_merge_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    HM_HIP(hipGetLastError());
+    e->n += 1;                                    // optimistic: corrected by hm_shard_loop_end
+    return HM_OK;
+}
+
+extern "C" int hm_shard_loop_end(hm_engine* e, int64_t steps, uint32_t* rec_out, int64_t* done, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_shard_loop_end: engine is NULL");
+    if (!e->shard_loop) return hm_fail(e, HM_E_STATE, "hm_shard_loop_end: no open loop");
+    if (!rec_out || !done || steps < 0 || steps > HM_LOOP_MAX_STEPS) return hm_fail(e, HM_E_ARG, "hm_shard_loop_end: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    e->shard_loop = false;
+    *done = 0;
+    if (steps > 0) {
+        HM_HIP(hipMemcpyAsync(e->h->loop_recs, e->d_loop_recs, sizeof(ArgminRec) * (size_t)steps, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipStreamSynchronize(s));
+        hm_unpack_recs(e->h->loop_recs, steps, rec_out, done);
+    }
+    e->n = e->shard_n0 + *done;
+    if (*done < steps) e->armed = false;          // a search that skipped itself armed nothing
+    return HM_OK;
+}

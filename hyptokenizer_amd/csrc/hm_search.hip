@@ -679,9 +679,14 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
         int rc0 = hm_launch_seed_init(e, a, s);
         if (rc0) return rc0;
     }
+    MergeFuse mf = kNoMerge;
+    if (e->shard_loop) {                          // inside hm_shard_loop_begin .. _end: a stopped loop skips its searches
+        a.stop = &e->d_loop->stop;
+        mf.loop = e->d_loop;
+    }
     HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, e->ev0, e->ev1));
     int rc = hm_launch_argmin_tail(e, a, sqrtf(c), thr, reinterpret_cast<ArgminRec*>(rec_dev), true, (int)req_rb,
-                                   req_re < 0 ? 0x7fffffff : (int)std::min<int64_t>(req_re, 0x7fffffff), true, kNoMerge, s);
+                                   req_re < 0 ? 0x7fffffff : (int)std::min<int64_t>(req_re, 0x7fffffff), true, mf, s);
     if (rc) return rc;
     // Armed optimistically: the host does not see this record.  Should the search have overflowed (found = 2, the
     // kernel then arms nothing), the next search of this range starts on the stale counters, reports found = 2 as

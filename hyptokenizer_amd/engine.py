@@ -264,6 +264,22 @@ class MergeEngine:
         nb = (float(b[1:2].view(np.float32)[0]), int(b[2]), int(b[3])) if b[0] == 1 else None
         return self._unpack(int(steps)), int(done.value), nb
 
+    # -- row-sharded device-resident loop ----------------------------------------------------------------
+    def shard_loop_begin(self) -> None:
+        self._chk(self._L.hm_shard_loop_begin(self._h, self._stream()))
+
+    def shard_merge_step(self, recs: torch.Tensor, world: int, c: float, table: torch.Tensor, step: int) -> None:
+        """Global nearest pair of the gathered records (int32 [world, 4] on this device) and its merge, on the device."""
+        t = self._check_table(table)
+        if recs.device != self.device or recs.dtype != torch.int32 or recs.numel() < 4 * world or not recs.is_contiguous():
+            raise ValueError("recs must be a contiguous int32[world * 4] tensor on the engine's device")
+        self._chk(self._L.hm_shard_merge_step(self._h, _ptr(recs), int(world), _f(c), _ptr(t), t.stride(0), int(step), self._stream()))
+
+    def shard_loop_end(self, steps: int):
+        done = C.c_int64(0)
+        self._chk(self._L.hm_shard_loop_end(self._h, int(steps), _np_ptr(self._rec_buf), C.byref(done), self._stream()))
+        return self._unpack(int(steps)), int(done.value)
+
     def debug_time_loops(self, on: bool) -> None:
         """Measurement aid: event pairs around every scan of the following ``std_merge_steps`` batches."""
         self._chk(self._L.hm_debug_time_loops(self._h, 1 if on else 0))

@@ -305,12 +305,19 @@ class HyperbolicTokenizer:
         the merge are this class's own (a subclass or an instance attribute that overrides them is
         honoured by falling back to the step-by-step loop), no row-sharding, an engine that has the loops."""
         cls = type(self)
-        return (self.device_loop and self.shard is None
+        if not (self.device_loop
                 and cls._merge_tokens is HyperbolicTokenizer._merge_tokens
                 and cls._best_candidate is HyperbolicTokenizer._best_candidate
                 and cls._append_token is HyperbolicTokenizer._append_token
-                and not ({"_merge_tokens", "_best_candidate", "_append_token"} & set(self.__dict__))
-                and hasattr(self._get_engine(), "std_merge_steps"))
+                and not ({"_merge_tokens", "_best_candidate", "_append_token"} & set(self.__dict__))):
+            return False
+        eng = self._get_engine()
+        if self.shard is None:
+            return hasattr(eng, "std_merge_steps")
+        # row-sharded: per step a search of the rank's rows, an all-gather of the records and the merge from the gathered
+        # records on every replica -- all enqueued, one synchronisation per batch (full search every step only)
+        return (not self.incremental and hasattr(eng, "shard_merge_step")
+                and getattr(eng, "device", None) is not None and eng.device.type == "cuda")
 
     def _sync_token_lengths(self, eng) -> None:
         n = self.current_vocab_size
@@ -334,7 +341,9 @@ class HyperbolicTokenizer:
                 k = min(k, 101 - n)               # the reference compares differently up to 100 tokens (:270-289): one threshold per batch
             self._sync_token_lengths(eng)
             thr = self._search_threshold()            # of the table as it is now; the same for every step of the batch
-            if self.incremental:
+            if self.shard is not None:
+                recs, done = self._sharded_batch(eng, thr, k)
+            elif self.incremental:
                 best = self._best_incremental()
                 recs, done, best_after = eng.incr_merge_steps(self.curvature, thr, self.embeddings.data, k, best)
             else:
@@ -360,6 +369,35 @@ class HyperbolicTokenizer:
                 else:
                     exhausted = True
         return merged, exhausted
+
+    def _sharded_batch(self, eng, thr: float, k: int):
+        """``k`` steps of the row-sharded loop without a host round trip per step: search of this rank's
+        rows -> record in device memory -> all-gather of the ranks' records on the same stream (RCCL) -> every rank
+        merges the global nearest pair into its replica (``hm_shard_merge_step``).  With a CPU process group (tests,
+        ranks sharing one GPU) the gather goes through the host and synchronises per step; the kernels are the same."""
+        import torch.distributed as dist
+        from ..sharding import partition_rows
+        ctx = self.shard
+        n0 = self.current_vocab_size
+        dev = eng.device
+        rec = ctx.record_buffer(dev)
+        gathered = torch.empty((k, 4 * ctx.world), dtype=torch.int32, device=dev)
+        table = self.embeddings.data
+        eng.shard_loop_begin()
+        try:
+            for s in range(k):
+                b = partition_rows(n0 + s, ctx.world)
+                eng.argmin_into(self.curvature, thr, b[ctx.rank], b[ctx.rank + 1], rec)
+                if ctx.device.type == "cuda":
+                    dist.all_gather_into_tensor(gathered[s], rec if rec.device == ctx.device else rec.to(ctx.device), group=ctx.group)
+                else:
+                    host = torch.empty(4 * ctx.world, dtype=torch.int32)
+                    dist.all_gather_into_tensor(host, rec.cpu(), group=ctx.group)
+                    gathered[s].copy_(host)
+                eng.shard_merge_step(gathered[s], ctx.world, self.curvature, table, s)
+        finally:
+            recs, done = eng.shard_loop_end(k)
+        return recs, done
 
     @_loop_without_cyclic_gc
     def optimize_merges(self, steps: int = 10000, log_every: int = 1000, parallel_eval: bool = True,

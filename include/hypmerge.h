@@ -175,6 +175,19 @@ int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev, int64_t l
 int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_dev, int64_t ld, int64_t steps, uint32_t* best_io,
                         uint32_t* rec_out, int64_t* done, void* stream);
 
+/* The same loop row-sharded over ranks, without a host round trip per step.  Between
+ * hm_shard_loop_begin and hm_shard_loop_end the caller enqueues, per step: hm_pairwise_argmin_dev over the rank's row
+ * range -> an all-gather of the ranks' 16-byte records on the same stream (RCCL) -> hm_shard_merge_step, which takes the
+ * lexicographic minimum of the `world` (<= 64) gathered records (identical on every rank) and applies the merge to this
+ * rank's replica (row = current row count, weights from the token lengths), or ends the loop on the device: no pair
+ * anywhere (record found = 0), an emission overflow on some rank (found = 2: the caller runs that step through the
+ * bounded host path); later steps of the batch then skip themselves (found = 3).  hm_shard_loop_end synchronises once
+ * and returns the step records as hm_std_merge_steps does. */
+int hm_shard_loop_begin(hm_engine* e, void* stream);
+int hm_shard_merge_step(hm_engine* e, const uint32_t* recs_dev, int world, float c, float* X_dev, int64_t ld, int64_t step,
+                        void* stream);
+int hm_shard_loop_end(hm_engine* e, int64_t steps, uint32_t* rec_out, int64_t* done, void* stream);
+
 /* Measurement aid: with on != 0, hm_std_merge_steps records a HIP event pair around every scan launch of a batch (all of
  * them enter hm_scan_totals) and around the whole batch; hm_last_loop_timing returns the last batch's wall time on the
  * device, the sum of its scan launches and its step count (0 when the batch stopped early). */

@@ -36,9 +36,25 @@ def _run(shard):
     out = {}
     tok = HyperbolicTokenizer(cjk_vocab(N), torch.nn.Parameter(X.clone()), merge_threshold=THR, device=dev, max_vocab_size=N + 512,
                               sign_convention="lorentz", shard=shard)
+    eng = tok._get_engine()
+    calls = [0]
+    inner = eng.shard_merge_step
+
+    def counted(*a, **k):
+        calls[0] += 1
+        return inner(*a, **k)
+    eng.shard_merge_step = counted
     tok.optimize_merges(steps=40, log_every=10 ** 9)
+    out["shard_merge_steps"] = calls[0]          # the sharded run goes through the device-resident batch
     out["std_merges"] = list(tok.merge_history)
     out["std_rows"] = tok.embeddings.data[N:tok.current_vocab_size].cpu().numpy().view(np.uint32).tolist()
+    # a loop that finds no candidate: the device-side stop at the first step and the skipped steps behind it
+    etok = HyperbolicTokenizer(cjk_vocab(N), torch.nn.Parameter(X.clone()), merge_threshold=THR, device=dev, max_vocab_size=N + 512,
+                               sign_convention="lorentz", shard=shard)
+    near = etok._get_engine().argmin(1.0, THR)                 # nearest pair of the untouched table (whole table: same on every rank)
+    etok.merge_threshold = float(np.float32(near[0]) * np.float32(0.98))     # nothing below it: the first step ends the loop
+    etok.optimize_merges(steps=60, log_every=10 ** 9)
+    out["exhaust_merges"] = list(etok.merge_history)
     random.seed(42)
     ftok = FastHyperbolicTokenizer(cjk_vocab(N), torch.nn.Parameter(X.clone()), merge_threshold=THR, device=dev,
                                    max_vocab_size=N + 512, sign_convention="lorentz", shard=shard, cache_size=500)
@@ -72,6 +88,7 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_process_run(world):
     os.environ["TQDM_DISABLE"] = "1"
     ref = _run(None)
     assert len(ref["std_merges"]) == 40 and len(ref["fast_merges"]) == 230 and ref["incr_merges"] == ref["std_merges"]
+    assert ref["exhaust_merges"] == []
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -82,7 +99,9 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_process_run(world):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    assert ref.pop("shard_merge_steps") == 0
     for r in range(world):
+        assert results[r].pop("shard_merge_steps") == 40, r      # every step through hm_shard_merge_step
         assert results[r] == ref, r
 
 
