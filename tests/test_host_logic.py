@@ -318,3 +318,19 @@ def test_reference_unit_test_properties(tmp_path):
 @pytest.mark.parametrize("mode", ["reference", "lorentz"])
 def test_cli_matches_reference(golden_dir, mode, tmp_path):
     check_cli(golden_dir, mode, tmp_path, OracleEngine)
+
+
+def test_pair_sampler_consumes_the_generator_like_random_sample():
+    """_compute_distance_statistics draws its pairs through _sample_pairs: same pairs and same generator state as the
+    reference's ``random.sample(range(n), 2)`` calls (fast_hyperbolic_merge.py:448-449), for large and tiny n."""
+    import random
+    from hyptokenizer_amd.tokenizer import fast_hyperbolic_merge as F
+    for n, count in ((50000, 1000), (22, 300), (21, 50), (5, 10), (2, 1)):
+        random.seed(1234 + n)
+        ii, jj = F._sample_pairs(n, count)
+        state = random.getstate()
+        random.seed(1234 + n)
+        want = [random.sample(range(n), 2) for _ in range(count)]
+        assert [w[0] for w in want] == ii and [w[1] for w in want] == jj
+        assert random.getstate() == state
+    assert F._PAIR_SAMPLER_OK is True          # the shortcut is in use on this interpreter
