@@ -24,8 +24,8 @@ inline uint32_t twist(uint32_t u, uint32_t v) { return (((u & UMASK) | (v & LMAS
 // One regeneration of the 624-word block.  Skipping the ~n draws a randperm(n) call makes beyond the prefix is 160 of
 // these at n = 100 000, i.e. nearly all of the helper's time, and the recurrence vectorises: word k reads k, k + 1 and
 // k + 397 (not yet rewritten) in the first 227 words, and k - 227 (rewritten 227 words earlier) afterwards -- no
-// dependence closer than 227 words.  Compiled for AVX2 and for the baseline ISA; the loader picks at run time.
-__attribute__((target_clones("avx2", "default"), optimize("O3", "tree-vectorize")))
+// dependence closer than 227 words.  Compiled for AVX-512, AVX2 and the baseline ISA; the loader picks at run time.
+__attribute__((target_clones("avx512f", "avx2", "default"), optimize("O3", "tree-vectorize")))
 void mt_regenerate(uint32_t* __restrict__ st)
 {
     constexpr int A = MT_N - MT_M;                 // 227
