@@ -684,7 +684,10 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
         a.stop = &e->d_loop->stop;
         mf.loop = e->d_loop;
     }
-    HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, e->ev0, e->ev1));
+    // (inside a sharded loop only the batch's first search carries timing events: reading them back at the next call is a
+    // host wait, and the point of the loop is that the host runs ahead of the device)
+    const bool timed = !e->shard_loop || e->n == e->shard_n0;
+    HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, timed ? e->ev0 : nullptr, timed ? e->ev1 : nullptr));
     int rc = hm_launch_argmin_tail(e, a, sqrtf(c), thr, reinterpret_cast<ArgminRec*>(rec_dev), true, (int)req_rb,
                                    req_re < 0 ? 0x7fffffff : (int)std::min<int64_t>(req_re, 0x7fffffff), true, mf, s);
     if (rc) return rc;
@@ -692,8 +695,10 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
     // kernel then arms nothing), the next search of this range starts on the stale counters, reports found = 2 as
     // well, and its caller takes the bounded host path -- slower, never wrong.
     e->armed = true; e->armed_rb = req_rb; e->armed_re = req_re;
-    e->pending_timing = true;
-    e->pending_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
+    if (timed) {
+        e->pending_timing = true;
+        e->pending_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
+    }
     return HM_OK;
 }
 
