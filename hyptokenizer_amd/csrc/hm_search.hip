@@ -424,6 +424,79 @@ __global__ __launch_bounds__(256) void hm_rank_merge_kernel(const uint4* __restr
     if (mine < total && me.y != 0xffffffffu && rank < k) out[rank] = me;
 }
 
+// ---- the same two kernels with the entry count taken from device memory (m = min(*m_dev, cap) + m_add): the
+// incremental refresh enqueues its whole chain -- scan, distances, union with the previous list, sort, read-back -- and
+// synchronises once; grids are sized for the most it accepts (HM_RANK_LIMIT entries), surplus blocks leave at once ----
+__device__ __forceinline__ uint32_t hm_dev_count(const unsigned long long* m_dev, uint32_t cap, uint32_t m_add)
+{
+    const unsigned long long v = *m_dev;
+    return (uint32_t)(v > (unsigned long long)cap ? cap : v) + m_add;
+}
+
+__global__ __launch_bounds__(256) void hm_append_prev_kernel(uint4* __restrict__ ent, const unsigned long long* __restrict__ m_dev, uint32_t cap,
+                                                             const uint4* __restrict__ prev, uint32_t k)
+{
+    const unsigned long long m_new = *m_dev;
+    if (m_new + (unsigned long long)k > (unsigned long long)cap) return;          // the host sees the count and falls back
+    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < k; t += gridDim.x * 256) ent[(uint32_t)m_new + t] = prev[t];
+}
+
+__global__ __launch_bounds__(1024) void hm_chunk_sort_dev_kernel(const uint4* __restrict__ ent, const unsigned long long* __restrict__ m_dev,
+                                                                 uint32_t cap, uint32_t m_add, uint4* __restrict__ out)
+{
+    __shared__ uint4 keys[HM_SORT_CHUNK];
+    const uint32_t m = hm_dev_count(m_dev, cap, m_add);
+    const uint32_t base = blockIdx.x * HM_SORT_CHUNK;
+    if (base >= m) return;                                                        // block-uniform
+    for (uint32_t q = threadIdx.x; q < HM_SORT_CHUNK; q += 1024) {
+        const uint32_t idx = base + q;
+        keys[q] = idx < m ? ent[idx] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0);
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= HM_SORT_CHUNK; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t t = threadIdx.x;
+            const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            const uint32_t hi = lo | j;
+            const bool up = (lo & k) == 0;
+            const uint4 x = keys[lo], y = keys[hi];
+            const bool swap = up ? hm_key_less(y.x, y.y, y.z, x.x, x.y, x.z) : hm_key_less(x.x, x.y, x.z, y.x, y.y, y.z);
+            if (swap) { keys[lo] = y; keys[hi] = x; }
+            __syncthreads();
+        }
+    }
+    for (uint32_t q = threadIdx.x; q < HM_SORT_CHUNK; q += 1024) out[base + q] = keys[q];
+}
+
+__global__ __launch_bounds__(256) void hm_rank_merge_dev_kernel(const uint4* __restrict__ chunks, const unsigned long long* __restrict__ m_dev,
+                                                                uint32_t cap, uint32_t m_add, uint4* __restrict__ out, uint32_t k)
+{
+    __shared__ uint4 tile[HM_SORT_CHUNK];
+    const uint32_t m = hm_dev_count(m_dev, cap, m_add);
+    const uint32_t nchunks = (m + HM_SORT_CHUNK - 1) / HM_SORT_CHUNK;
+    const uint32_t total = nchunks * HM_SORT_CHUNK;
+    if (blockIdx.x * 256 >= total) return;                                        // block-uniform
+    const uint32_t mine = blockIdx.x * 256 + threadIdx.x;
+    uint4 me = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0);
+    if (mine < total) me = chunks[mine];
+    const uint32_t my_chunk = mine / HM_SORT_CHUNK;
+    uint32_t rank = mine % HM_SORT_CHUNK;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < HM_SORT_CHUNK; q += 256) tile[q] = chunks[c * HM_SORT_CHUNK + q];
+        __syncthreads();
+        if (c == my_chunk) continue;
+        uint32_t lo = 0, hi = HM_SORT_CHUNK;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint4 o = tile[mid];
+            if (hm_key_less(o.x, o.y, o.z, me.x, me.y, me.z)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+    }
+    if (mine < total && me.y != 0xffffffffu && rank < k) out[rank] = me;
+}
+
 // exact selection of the k smallest keys among m entries of `src` (keys unique; invalid = 0xffffffff)
 // result in e->sorted.  `other` is scratch of the same capacity.
 static int hm_select_sorted(hm_engine* e, uint4* src, uint4* other, uint32_t m, uint32_t k, hipStream_t s)
@@ -786,30 +859,39 @@ static int hm_topk_incremental(hm_engine* e, float c, float thr, int64_t k, hipS
     hm_flush_pending_timing(e);
     e->last_scan_ms = 0.f; e->last_pairs = 0; e->last_emitted = 0; e->last_passes = 0;
     const Bounds b = hm_bounds(thr, c);
-    uint32_t m_new = 0;
+    // entries the sort below takes: the pairs of a few hundred new rows under the previous list's cut are often several
+    // ten thousand; 64 chunks keep the rank merge around 0.1 ms, beyond that the full search's radix narrowing is used
+    const uint32_t lim = std::min<uint32_t>(e->ent_cap, 64u * HM_SORT_CHUNK);
+    if ((uint64_t)k + 1 > lim) return HM_E_CAPACITY;
+    HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
+    HM_HIP(hipMemsetAsync(e->d_ctr64, 0, sizeof(unsigned long long) * 4, s));
     if (e->n > e->prev_n) {
         ScanArgs a; dim3 grid;
         if (!hm_prepare_scan(e, b, 0, -1, a, grid, -1, e->prev_n)) return hm_fail(e, HM_E_STATE, "incremental refresh: empty scan");
         a.count_sure = 0;
         a.cut_bits = e->last_cut_bits + HM_TIE_SLACK;
         a.tie_imax = 0x7fffffff;
-        HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
-        HM_HIP(hipMemsetAsync(e->d_ctr64, 0, sizeof(unsigned long long) * 4, s));
         HM_HIP(hm_launch_scan(e, HM_MODE_TOPK, a, grid, s));
         hipLaunchKernelGGL(hm_post_distance_kernel, dim3(256), dim3(256), 0, s, e->ent, e->d_ctr64, e->ent_cap, e->img, e->RS, e->d,
                            e->sign_mode, sqrtf(c), thr, a.cut_bits, a.tie_imax, e->d_ctr + 1);
         HM_HIP(hipGetLastError());
-        HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_ctr64, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, s));
-        HM_HIP(hipStreamSynchronize(s));
         e->last_passes = 1;
-        e->last_emitted = (int64_t)e->h->ctr64[2];
-        if (e->h->ctr64[2] + (uint64_t)k > (uint64_t)e->ent_cap) return HM_E_CAPACITY;     // (caller falls back to the full search)
-        m_new = (uint32_t)e->h->ctr64[2];
     }
-    // union: the new entries (already in e->ent, invalid ones carry all-ones keys) + the previous list
-    HM_HIP(hipMemcpyAsync(e->ent + m_new, e->d_prev, sizeof(uint4) * (size_t)k, hipMemcpyDeviceToDevice, s));
-    const int rc = hm_select_sorted(e, e->ent, e->ent2, m_new + (uint32_t)k, (uint32_t)k, s);
-    if (rc) return rc;
+    // union with the previous list (appended behind the new entries; invalid new entries carry all-ones keys), sorted
+    // outright, everything enqueued: the count of new entries stays on the device until the one synchronisation below
+    const unsigned long long* m_dev = e->d_ctr64 + 2;
+    const uint32_t room = lim - (uint32_t)k;                                       // new entries the sort can take
+    hipLaunchKernelGGL(hm_append_prev_kernel, dim3(64), dim3(256), 0, s, e->ent, m_dev, lim, e->d_prev, (uint32_t)k);
+    const uint32_t max_chunks = (lim + HM_SORT_CHUNK - 1) / HM_SORT_CHUNK;
+    hipLaunchKernelGGL(hm_chunk_sort_dev_kernel, dim3(max_chunks), dim3(1024), 0, s, e->ent, m_dev, room, (uint32_t)k, e->ent2);
+    hipLaunchKernelGGL(hm_rank_merge_dev_kernel, dim3(max_chunks * (HM_SORT_CHUNK / 256)), dim3(256), 0, s, e->ent2, m_dev, room, (uint32_t)k,
+                       e->sorted, (uint32_t)k);
+    HM_HIP(hipGetLastError());
+    HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_ctr64, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, s));
+    HM_HIP(hipMemcpyAsync(e->h_sorted, e->sorted, sizeof(uint4) * (size_t)k, hipMemcpyDeviceToHost, s));
+    HM_HIP(hipStreamSynchronize(s));
+    e->last_emitted = (int64_t)e->h->ctr64[2];
+    if (e->h->ctr64[2] > (unsigned long long)room) return HM_E_CAPACITY;          // too many new entries: the caller runs the full search
     *kk_out = (uint32_t)k;
     return HM_OK;
 }
@@ -848,10 +930,12 @@ static int hm_topk_impl(hm_engine* e, float c, float thr, int64_t k, int64_t row
         rc = hm_select_sorted(e, res, e->ent2, m, kk, s);
         if (rc) return rc;
     }
-    HM_HIP(hipMemcpyAsync(e->h_sorted, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToHost, s));
     const bool keep = (kk == k && whole);
-    if (keep) HM_HIP(hipMemcpyAsync(e->d_prev, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToDevice, s));
-    HM_HIP(hipStreamSynchronize(s));
+    if (keep) HM_HIP(hipMemcpyAsync(e->d_prev, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToDevice, s));    // (stream-ordered: no wait needed for it)
+    if (!done) {                                   // (the incremental refresh has read its list back already)
+        HM_HIP(hipMemcpyAsync(e->h_sorted, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipStreamSynchronize(s));
+    }
     uint32_t mx = 0;
     for (uint32_t t = 0; t < kk; ++t) {
         union { uint32_t u; float f; } cv; cv.u = e->h_sorted[t].x;
