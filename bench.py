@@ -470,7 +470,7 @@ def main() -> None:
         tf = time.perf_counter() - tf0
         fast = {"merges_per_s": (len(ftok.merge_history) - 202) / tf, "steps": fsteps - 202,
                 "note": "FastHyperbolicTokenizer.optimize_merges: cache of 10000, one exact top-k search per ~101 steps; "
-                        "the merges between two refreshes are issued as one launch"}
+                        "the merges between two refreshes are issued as one launch, the next refresh is enqueued behind them"}
         del ftok
 
     # incremental figure (SURVEY 8(d) variant (ii)): same merges, nearest pair maintained with one

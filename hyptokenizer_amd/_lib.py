@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = (
     "hm_merge_append_batch", "hm_truncate", "hm_set_token_lengths", "hm_std_merge_steps", "hm_incr_merge_steps",
     "hm_coherence_batch", "hm_project_table", "hm_debug_force_cut", "hm_randperm_prefix", "hm_merge_append_batch_host",
     "hm_tokenize_table_capacity", "hm_tokenize_build_table", "hm_tokenize_batch", "hm_debug_time_loops", "hm_last_loop_timing", "hm_shard_loop_begin", "hm_shard_merge_step", "hm_shard_loop_end",
+    "hm_topk_refresh_begin", "hm_topk_refresh_end",
 )
 
 
@@ -88,6 +89,8 @@ def load() -> C.CDLL:
     L.hm_randperm_prefix.argtypes = [vp, pi32, C.POINTER(C.c_uint32), i64, i32, i64, vp]
     L.hm_debug_time_loops.argtypes = [vp, C.c_int]
     L.hm_shard_loop_begin.argtypes = [vp, vp]
+    L.hm_topk_refresh_begin.argtypes = [vp, f32, f32, i64, vp]
+    L.hm_topk_refresh_end.argtypes = [vp, vp, vp, vp, pi64]
     L.hm_shard_merge_step.argtypes = [vp, vp, C.c_int, f32, vp, i64, i64, vp]
     L.hm_shard_loop_end.argtypes = [vp, i64, vp, pi64, vp]
     L.hm_last_loop_timing.argtypes = [vp, pf32, pf32, pi64]

@@ -189,6 +189,11 @@ struct hm_engine {
     int64_t prev_k = 0, prev_n = 0;
     float prev_thr = 0.f;
     bool debug_cut = false;               // hm_debug_force_cut: the next top-k starts from last_cut_bits as given
+    // hm_topk_refresh_begin .. _end
+    bool refresh_pending = false;
+    int64_t refresh_k = 0;
+    float refresh_c = 0.f, refresh_thr = 0.f;
+    void* refresh_stream = nullptr;
     // row-sharded device-resident loop (hm_shard_loop_begin .. _end): searches skip themselves once the loop has stopped
     bool shard_loop = false;
     int64_t shard_n0 = 0;

@@ -853,15 +853,24 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
 // are therefore the k smallest of S[:k] + the pairs that involve a NEW row (j >= prev_n).  Only the last column
 // tile(s) are scanned (cut = largest u' of S[:k], so every new pair that could enter is emitted) and the two lists
 // are merged by the exact selection.  Preconditions checked by the caller; the exact total is not produced here.
-static int hm_topk_incremental(hm_engine* e, float c, float thr, int64_t k, hipStream_t s, uint32_t* kk_out)
+// when the incremental refresh applies (checked by its callers)
+static bool hm_topk_incremental_ok(const hm_engine* e, float c, float thr, int64_t k)
 {
-    *kk_out = 0;
+    return k > 0 && e->incremental_topk && e->have_cut && e->prev_valid && e->prev_k == k && e->last_cut_c == c && thr >= e->prev_thr &&
+           e->n >= e->prev_n && e->n - e->prev_n <= 8192 && e->last_cut_bits > 0x3f800000u && !e->debug_cut;
+}
+
+// entries the device-side sort takes: the pairs of a few hundred new rows under the previous list's cut are often several
+// ten thousand; 64 chunks keep the rank merge around 0.1 ms, beyond that the full search's radix narrowing is used
+static uint32_t hm_topk_incremental_limit(const hm_engine* e) { return std::min<uint32_t>(e->ent_cap, 64u * HM_SORT_CHUNK); }
+
+// everything of the incremental refresh up to the read-back, enqueued; no host wait
+static int hm_topk_incremental_enqueue(hm_engine* e, float c, float thr, int64_t k, hipStream_t s)
+{
     hm_flush_pending_timing(e);
     e->last_scan_ms = 0.f; e->last_pairs = 0; e->last_emitted = 0; e->last_passes = 0;
     const Bounds b = hm_bounds(thr, c);
-    // entries the sort below takes: the pairs of a few hundred new rows under the previous list's cut are often several
-    // ten thousand; 64 chunks keep the rank merge around 0.1 ms, beyond that the full search's radix narrowing is used
-    const uint32_t lim = std::min<uint32_t>(e->ent_cap, 64u * HM_SORT_CHUNK);
+    const uint32_t lim = hm_topk_incremental_limit(e);
     if ((uint64_t)k + 1 > lim) return HM_E_CAPACITY;
     HM_HIP(hipMemsetAsync(e->d_ctr, 0, sizeof(uint32_t) * 8, s));
     HM_HIP(hipMemsetAsync(e->d_ctr64, 0, sizeof(unsigned long long) * 4, s));
@@ -878,7 +887,7 @@ static int hm_topk_incremental(hm_engine* e, float c, float thr, int64_t k, hipS
         e->last_passes = 1;
     }
     // union with the previous list (appended behind the new entries; invalid new entries carry all-ones keys), sorted
-    // outright, everything enqueued: the count of new entries stays on the device until the one synchronisation below
+    // outright: the count of new entries stays on the device
     const unsigned long long* m_dev = e->d_ctr64 + 2;
     const uint32_t room = lim - (uint32_t)k;                                       // new entries the sort can take
     hipLaunchKernelGGL(hm_append_prev_kernel, dim3(64), dim3(256), 0, s, e->ent, m_dev, lim, e->d_prev, (uint32_t)k);
@@ -889,53 +898,35 @@ static int hm_topk_incremental(hm_engine* e, float c, float thr, int64_t k, hipS
     HM_HIP(hipGetLastError());
     HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_ctr64, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, s));
     HM_HIP(hipMemcpyAsync(e->h_sorted, e->sorted, sizeof(uint4) * (size_t)k, hipMemcpyDeviceToHost, s));
+    return HM_OK;
+}
+
+// the one synchronisation; HM_E_CAPACITY: too many new entries for the device-side sort (the caller runs the full search)
+static int hm_topk_incremental_finish(hm_engine* e, int64_t k, hipStream_t s, uint32_t* kk_out)
+{
+    *kk_out = 0;
     HM_HIP(hipStreamSynchronize(s));
     e->last_emitted = (int64_t)e->h->ctr64[2];
-    if (e->h->ctr64[2] > (unsigned long long)room) return HM_E_CAPACITY;          // too many new entries: the caller runs the full search
+    if (e->h->ctr64[2] > (unsigned long long)(hm_topk_incremental_limit(e) - (uint32_t)k)) return HM_E_CAPACITY;
     *kk_out = (uint32_t)k;
     return HM_OK;
 }
 
-// common body of hm_pairwise_topk / hm_pairwise_topk_nocount
-static int hm_topk_impl(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, bool want_count,
-                        float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count, void* stream)
+// While rows are only appended, the k smallest keys of the grown table are the k smallest of (the previous
+// list) + (the pairs that involve a NEW row, j >= prev_n): only the last column tiles are scanned (cut = largest u' of
+// the previous list, so every new pair that could enter is emitted) and the union is sorted exactly.
+static int hm_topk_incremental(hm_engine* e, float c, float thr, int64_t k, hipStream_t s, uint32_t* kk_out)
 {
-    if (e) e->armed = false;
-    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pairwise_topk: engine is NULL");
-    if (!n_out || !count || k < 0 || (k > 0 && (!d_out || !i_out || !j_out)))
-        return hm_fail(e, HM_E_ARG, "hm_pairwise_topk: bad output pointers / k");
-    if (!(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pairwise_topk: curvature must be > 0");
-    if (k > (int64_t)e->sorted_cap) return hm_fail(e, HM_E_CAPACITY, "hm_pairwise_topk: k > 65536");
-    hipStream_t s = (hipStream_t)stream;
-    HM_HIP(hipSetDevice(e->device));
-    *n_out = 0; *count = 0;
-    const bool whole = row_begin <= 0 && (row_end < 0 || row_end >= e->n - 1);
-    uint32_t kk = 0;
-    bool done = false;
-    if (!want_count && k > 0 && whole && e->incremental_topk && e->have_cut && e->prev_valid && e->prev_k == k && e->last_cut_c == c &&
-        thr >= e->prev_thr && e->n >= e->prev_n && e->n - e->prev_n <= 8192 && e->last_cut_bits > 0x3f800000u && !e->debug_cut) {
-        const int rc = hm_topk_incremental(e, c, thr, k, s, &kk);
-        if (rc == HM_OK) { done = true; *count = -1; }
-        else if (rc != HM_E_CAPACITY) return rc;
-    }
-    if (!done) {
-        int64_t valid = 0, total = 0;
-        uint4* res = nullptr;
-        int rc = hm_topk_core(e, c, thr, k, row_begin, row_end, false, want_count || k == 0, -1, &valid, &total, &res, s);
-        if (rc) return rc;
-        *count = total;
-        kk = (uint32_t)std::min<int64_t>(k, valid);
-        if (kk == 0 || !res) { e->prev_valid = false; return HM_OK; }
-        const uint32_t m = (uint32_t)std::min<uint64_t>(e->h->ctr64[2], e->ent_cap);
-        rc = hm_select_sorted(e, res, e->ent2, m, kk, s);
-        if (rc) return rc;
-    }
-    const bool keep = (kk == k && whole);
-    if (keep) HM_HIP(hipMemcpyAsync(e->d_prev, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToDevice, s));    // (stream-ordered: no wait needed for it)
-    if (!done) {                                   // (the incremental refresh has read its list back already)
-        HM_HIP(hipMemcpyAsync(e->h_sorted, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToHost, s));
-        HM_HIP(hipStreamSynchronize(s));
-    }
+    *kk_out = 0;
+    const int rc = hm_topk_incremental_enqueue(e, c, thr, k, s);
+    if (rc) return rc;
+    return hm_topk_incremental_finish(e, k, s, kk_out);
+}
+
+// host side of a finished top-k search whose ordered list sits in e->h_sorted: outputs and the state the next refresh uses
+static void hm_topk_publish(hm_engine* e, uint32_t kk, int64_t k, float c, float thr, bool keep, float* d_out, int32_t* i_out, int32_t* j_out,
+                            int64_t* n_out)
+{
     uint32_t mx = 0;
     for (uint32_t t = 0; t < kk; ++t) {
         union { uint32_t u; float f; } cv; cv.u = e->h_sorted[t].x;
@@ -958,6 +949,48 @@ static int hm_topk_impl(hm_engine* e, float c, float thr, int64_t k, int64_t row
         e->have_cut = false;
         e->prev_valid = false;
     }
+}
+
+// common body of hm_pairwise_topk / hm_pairwise_topk_nocount
+static int hm_topk_impl(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, bool want_count,
+                        float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count, void* stream)
+{
+    if (e) e->armed = false;
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_pairwise_topk: engine is NULL");
+    if (!n_out || !count || k < 0 || (k > 0 && (!d_out || !i_out || !j_out)))
+        return hm_fail(e, HM_E_ARG, "hm_pairwise_topk: bad output pointers / k");
+    if (!(c > 0.0f)) return hm_fail(e, HM_E_ARG, "hm_pairwise_topk: curvature must be > 0");
+    if (k > (int64_t)e->sorted_cap) return hm_fail(e, HM_E_CAPACITY, "hm_pairwise_topk: k > 65536");
+    hipStream_t s = (hipStream_t)stream;
+    HM_HIP(hipSetDevice(e->device));
+    *n_out = 0; *count = 0;
+    const bool whole = row_begin <= 0 && (row_end < 0 || row_end >= e->n - 1);
+    uint32_t kk = 0;
+    bool done = false;
+    if (!want_count && whole && hm_topk_incremental_ok(e, c, thr, k)) {
+        const int rc = hm_topk_incremental(e, c, thr, k, s, &kk);
+        if (rc == HM_OK) { done = true; *count = -1; }
+        else if (rc != HM_E_CAPACITY) return rc;
+    }
+    if (!done) {
+        int64_t valid = 0, total = 0;
+        uint4* res = nullptr;
+        int rc = hm_topk_core(e, c, thr, k, row_begin, row_end, false, want_count || k == 0, -1, &valid, &total, &res, s);
+        if (rc) return rc;
+        *count = total;
+        kk = (uint32_t)std::min<int64_t>(k, valid);
+        if (kk == 0 || !res) { e->prev_valid = false; return HM_OK; }
+        const uint32_t m = (uint32_t)std::min<uint64_t>(e->h->ctr64[2], e->ent_cap);
+        rc = hm_select_sorted(e, res, e->ent2, m, kk, s);
+        if (rc) return rc;
+    }
+    const bool keep = (kk == k && whole);
+    if (keep) HM_HIP(hipMemcpyAsync(e->d_prev, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToDevice, s));    // (stream-ordered: no wait needed for it)
+    if (!done) {                                   // (the incremental refresh has read its list back already)
+        HM_HIP(hipMemcpyAsync(e->h_sorted, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToHost, s));
+        HM_HIP(hipStreamSynchronize(s));
+    }
+    hm_topk_publish(e, kk, k, c, thr, keep, d_out, i_out, j_out, n_out);
     return HM_OK;
 }
 
@@ -971,6 +1004,40 @@ extern "C" int hm_pairwise_topk_nocount(hm_engine* e, float c, float thr, int64_
                                         float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count, void* stream)
 {
     return hm_topk_impl(e, c, thr, k, row_begin, row_end, false, d_out, i_out, j_out, n_out, count, stream);
+}
+
+// The refresh of a table whose rows were only appended since the last whole-table top-k search, in two halves: begin
+// enqueues the whole chain and returns; end waits and delivers.  Between the two the engine must not be used.
+extern "C" int hm_topk_refresh_begin(hm_engine* e, float c, float thr, int64_t k, void* stream)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_topk_refresh_begin: engine is NULL");
+    if (e->refresh_pending) return hm_fail(e, HM_E_STATE, "hm_topk_refresh_begin: a refresh is already pending");
+    if (!(c > 0.0f) || k <= 0 || k > (int64_t)e->sorted_cap) return hm_fail(e, HM_E_ARG, "hm_topk_refresh_begin: bad arguments");
+    if (!hm_topk_incremental_ok(e, c, thr, k)) return HM_E_STATE;                  // (no message: "not applicable" is an ordinary answer)
+    HM_HIP(hipSetDevice(e->device));
+    e->armed = false;
+    const int rc = hm_topk_incremental_enqueue(e, c, thr, k, (hipStream_t)stream);
+    if (rc) return rc;
+    e->refresh_pending = true;
+    e->refresh_k = k; e->refresh_c = c; e->refresh_thr = thr; e->refresh_stream = stream;
+    return HM_OK;
+}
+
+extern "C" int hm_topk_refresh_end(hm_engine* e, float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_topk_refresh_end: engine is NULL");
+    if (!e->refresh_pending) return hm_fail(e, HM_E_STATE, "hm_topk_refresh_end: no refresh pending");
+    if (!d_out || !i_out || !j_out || !n_out) return hm_fail(e, HM_E_ARG, "hm_topk_refresh_end: NULL output pointer");
+    HM_HIP(hipSetDevice(e->device));
+    e->refresh_pending = false;
+    hipStream_t s = (hipStream_t)e->refresh_stream;
+    *n_out = 0;
+    uint32_t kk = 0;
+    const int rc = hm_topk_incremental_finish(e, e->refresh_k, s, &kk);
+    if (rc) return rc;                                                             // HM_E_CAPACITY: run hm_pairwise_topk_nocount instead
+    HM_HIP(hipMemcpyAsync(e->d_prev, e->sorted, sizeof(uint4) * kk, hipMemcpyDeviceToDevice, s));
+    hm_topk_publish(e, kk, e->refresh_k, e->refresh_c, e->refresh_thr, true, d_out, i_out, j_out, n_out);
+    return HM_OK;
 }
 
 extern "C" int hm_pairwise_count(hm_engine* e, float c, float thr, int64_t n_limit, int64_t* count, void* stream)

@@ -73,6 +73,7 @@ class MergeEngine:
         _lib.check(self._L.hm_engine_create(C.byref(self._h), self.device.index, self.max_rows, self.d1,
                                             self.sign_mode, PREFILTERS[prefilter]))
         self._rec_buf = np.zeros(4 * _lib.LOOP_MAX_STEPS, np.uint32)
+        self._refresh_k = None       # k of a pending topk_refresh_begin
 
     # ------------------------------------------------------------------------------------------
     def close(self) -> None:
@@ -87,6 +88,8 @@ class MergeEngine:
             pass
 
     def _stream(self) -> C.c_void_p:
+        if getattr(self, "_refresh_k", None) is not None:
+            raise RuntimeError("a top-k refresh is pending on this engine: call topk_refresh_end() first")
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _chk(self, st: int) -> None:
@@ -153,6 +156,35 @@ class MergeEngine:
                      _np_ptr(d), _np_ptr(i), _np_ptr(j), C.byref(n_out), C.byref(total), self._stream()))
         m = int(n_out.value)
         return d[:m], i[:m], j[:m], int(total.value)
+
+    def topk_refresh_begin(self, c: float, thr: float, k: int) -> bool:
+        """Enqueue the refresh of a table that only grew since the last whole-table ``topk`` and return at once
+        (``False``: not of that kind -- use ``topk``).  Nothing else may be asked of the engine until
+        ``topk_refresh_end``."""
+        st = self._L.hm_topk_refresh_begin(self._h, _f(c), float(thr), int(k), self._stream())
+        if st == -3:                               # HM_E_STATE without a message: the refresh is not of the incremental kind
+            return False
+        self._chk(st)
+        self._refresh_k = int(k)
+        return True
+
+    def topk_refresh_end(self):
+        """Wait for the refresh -> (d, i, j), or ``None`` when it has to be redone through ``topk`` (more new entries
+        than the device-side sort takes)."""
+        k = self._refresh_k
+        if k is None:
+            raise RuntimeError("no refresh pending")
+        self._refresh_k = None
+        d = np.empty(k, np.float32)
+        i = np.empty(k, np.int32)
+        j = np.empty(k, np.int32)
+        n_out = C.c_int64(0)
+        st = self._L.hm_topk_refresh_end(self._h, _np_ptr(d), _np_ptr(i), _np_ptr(j), C.byref(n_out))
+        if st == -2:                               # HM_E_CAPACITY
+            return None
+        self._chk(st)
+        m = int(n_out.value)
+        return d[:m], i[:m], j[:m]
 
     def count_candidates(self, c: float, thr: float, n_limit: int = -1) -> int:
         """Exact number of candidates among the first ``n_limit`` rows (-1: all live rows)."""

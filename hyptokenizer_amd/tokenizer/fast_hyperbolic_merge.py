@@ -283,11 +283,35 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         self.lazy_count = True        # refreshes do not count every candidate; len(candidates) counts on demand
         self.batch_merges = True      # the merges between two refreshes go to the engine as one launch
         self._refreshed = None        # the CandidateList of this step's refresh (None on a cache pop)
+        # When a refresh returns, every merge up to the NEXT refresh is known and issued (``_plan_merges``), so the table
+        # of the next refresh exists on the device long before the loop's string bookkeeping gets there: its search is
+        # enqueued right behind the merges (``topk_refresh_begin``) and collected when the loop arrives -- used only if
+        # the loop arrives in exactly the state it was started for.
+        self.prefetch_refresh = True
+        self._prefetch = None         # key (engine id, rows, threshold, curvature, k) of a refresh in flight
+        self._prefetched = None       # (key, (d, i, j) | None) of a finished one
 
     def _build_faiss_index(self) -> None:
         """Reference ``:195-240``.  The HNSW index is replaced by the exact search: nothing to build."""
         self.use_approximate_search = False
         self.index = None
+
+    def _finish_prefetch(self) -> None:
+        """Nothing else may be asked of the engine while a prefetched refresh is in flight: collect it first."""
+        key = getattr(self, "_prefetch", None)
+        if key is not None:
+            self._prefetch = None
+            self._prefetched = (key, self._engine.topk_refresh_end())
+
+    def _get_engine(self):
+        self._finish_prefetch()
+        return super()._get_engine()
+
+    def _cancel_plan(self) -> None:
+        if self._plan is not None:        # rows issued ahead of time are about to be dropped: so is a refresh made with them
+            self._finish_prefetch()
+            self._prefetched = None
+        super()._cancel_plan()
 
     def _find_merge_candidates(self) -> List[Tuple[int, int, float]]:
         """Base-class tuple format (reference ``:242-251``); holds the materialised candidates."""
@@ -313,8 +337,17 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
             d, i, j, total = sharded_topk(eng, self.shard, c, thr, self.cache.max_size)
             found = CandidateList(d, i, j, total)
         elif self.lazy_count and hasattr(eng, "count_candidates"):
-            d, i, j, total = eng.topk(c, thr, self.cache.max_size, count=False)
-            found = CandidateList(d, i, j, total, counter=lambda: eng.count_candidates(c, thr, n0))
+            got, self._prefetched = self._prefetched, None          # (_get_engine above has collected a refresh in flight)
+            if got is not None and got[1] is not None and got[0] == (id(eng), n0, thr, float(c), self.cache.max_size):
+                d, i, j = got[1]
+                total = -1
+            else:
+                d, i, j, total = eng.topk(c, thr, self.cache.max_size, count=False)
+
+            def count_all():
+                self._finish_prefetch()
+                return eng.count_candidates(c, thr, n0)
+            found = CandidateList(d, i, j, total, counter=count_all)
         else:
             d, i, j, total = eng.topk(c, thr, self.cache.max_size)
             found = CandidateList(d, i, j, total)
@@ -411,6 +444,13 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
                                independent=bool(max(int(ii.max()), int(jj.max())) < n))
         from .hyperbolic_merge import _MergePlan
         self._plan = _MergePlan(ii.tolist(), jj.tolist(), n)
+        if (self.prefetch_refresh and self.lazy_count and self._prefetch is None and hasattr(eng, "topk_refresh_begin")
+                and count == 1 + (stored + 99) // 100 and steps_left > count):
+            # the loop refreshes next when these `count` merges are done: at n + count rows, same threshold
+            c = float(self.curvature)
+            thr = self._search_threshold(n + count)
+            if eng.topk_refresh_begin(c, thr, self.cache.max_size):
+                self._prefetch = (id(eng), n + count, thr, c, self.cache.max_size)
 
     def _merge_tokens(self, i: int, j: int) -> None:
         super()._merge_tokens(i, j)

@@ -102,6 +102,14 @@ int hm_pairwise_topk(hm_engine* e, float c, float thr, int64_t k, int64_t row_be
  * total only in log lines (fast_hyperbolic_merge.py:521,526) and for emptiness (:529). */
 int hm_pairwise_topk_nocount(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end,
                              float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count, void* stream);
+/* The same refresh in two halves for callers that have host work to do meanwhile (the fast tokenizer's string
+ * bookkeeping): hm_topk_refresh_begin enqueues the whole chain and returns at once -- HM_E_STATE (without a message) when
+ * the refresh is not of the incremental kind (rows changed, other k / curvature, lower threshold: use
+ * hm_pairwise_topk_nocount) --, hm_topk_refresh_end waits and delivers the ordered list (HM_E_CAPACITY: more new entries
+ * than the device-side sort takes; the state is untouched, run hm_pairwise_topk_nocount).  No other call on the engine in
+ * between. */
+int hm_topk_refresh_begin(hm_engine* e, float c, float thr, int64_t k, void* stream);
+int hm_topk_refresh_end(hm_engine* e, float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out);
 /* Exact number of candidates among the first n_limit rows (n_limit < 0: all live rows).  Rows are only ever
  * appended, so this is len(candidates) of the search that ran when the table had n_limit rows. */
 int hm_pairwise_count(hm_engine* e, float c, float thr, int64_t n_limit, int64_t* count, void* stream);

@@ -354,3 +354,45 @@ def test_fast_loop_batched_merges_equal_step_by_step():
     assert torch.equal(a.embeddings.data[:n + 8].view(torch.int32), b.embeddings.data[:n + 8].view(torch.int32))
     assert a.merge_threshold == b.merge_threshold and len(a.cache) == len(b.cache)
     assert a.last_run_stats["num_candidates"] == b.last_run_stats["num_candidates"]
+
+
+def test_fast_loop_prefetched_refreshes_equal_synchronous_ones():
+    """the next refresh is enqueued behind the planned merges (topk_refresh_begin) and collected when the loop gets there:
+    same history, rows, thresholds and candidate counts as with synchronous refreshes -- and the prefetched lists are
+    really the ones consumed; log lines, statistics and a threshold rescale in between must not disturb it"""
+    from hyptokenizer_amd.tokenizer.fast_hyperbolic_merge import FastHyperbolicTokenizer
+    V, d = 6000, 48
+    X = lorentz_table(V, d, seed=17, scale=0.05)
+    runs, used = [], []
+    for prefetch in (True, False):
+        import random
+        random.seed(5)
+        tok = FastHyperbolicTokenizer(cjk_vocab(V), torch.nn.Parameter(X.clone()), merge_threshold=0.5, max_vocab_size=V + 1400,
+                                      sign_convention="lorentz", cache_size=2500)
+        tok.prefetch_refresh = prefetch
+        eng = tok._get_engine()
+        ends = [0, 0]
+        inner = eng.topk_refresh_end
+
+        def counted(_inner=inner, _ends=ends):
+            out = _inner()
+            _ends[0] += 1
+            _ends[1] += out is not None
+            return out
+        eng.topk_refresh_end = counted
+        tok.optimize_merges(steps=1230, log_every=400)          # crosses step 1000: the adaptive threshold is rescaled there
+        runs.append(tok)
+        used.append(ends)
+    a, b = runs
+    assert used[1] == [0, 0] and used[0][0] >= 10 and used[0][1] >= 8        # refreshes in flight were collected and delivered lists
+    assert a.merge_history == b.merge_history and len(a.merge_history) == 1230
+    n = a.current_vocab_size
+    assert torch.equal(a.embeddings.data[:n + 8].view(torch.int32), b.embeddings.data[:n + 8].view(torch.int32))
+    assert a.merge_threshold == b.merge_threshold and len(a.cache) == len(b.cache)
+    assert a.last_run_stats["num_candidates"] == b.last_run_stats["num_candidates"]
+    # the engine refuses other work while a refresh is in flight
+    eng = a._get_engine()
+    if eng.topk_refresh_begin(1.0, a._search_threshold(), a.cache.max_size):
+        with pytest.raises(RuntimeError):
+            eng.argmin(1.0, 0.5)
+        eng.topk_refresh_end()
