@@ -22,13 +22,21 @@ for t in range(seqs):
     rec = torch.zeros(4, dtype=torch.int32, device="cuda")
     log = []
     for step in range(14):
-        op = str(rng.choice(["argmin", "argmin", "argmin", "topk", "merge", "merge", "edit", "range", "dev", "rowmin", "thr"]))
+        op = str(rng.choice(["argmin", "argmin", "argmin", "topk", "topk_nc", "refresh", "merge", "merge", "merges", "edit", "range", "dev", "rowmin", "thr"]))
         log.append(op)
         try:
             if op == "merge" and n < cap - 1:
                 i, j = int(rng.integers(n)), int(rng.integers(n)); w = float(rng.random())
                 X[n] = O.midpoint_batch(X[:n], np.array([i], np.int32), np.array([j], np.int32), np.array([w], np.float32), 1.0, sm)[0]
                 eng.merge_append(i, j, w, 1.0, table, n); n += 1
+                continue
+            if op == "merges":                     # a handful of appended rows: what a fast-tokenizer cycle does before its refresh
+                for _ in range(int(rng.integers(1, 6))):
+                    if n >= cap - 1:
+                        break
+                    i, j = int(rng.integers(n)), int(rng.integers(n)); w = float(rng.random())
+                    X[n] = O.midpoint_batch(X[:n], np.array([i], np.int32), np.array([j], np.int32), np.array([w], np.float32), 1.0, sm)[0]
+                    eng.merge_append(i, j, w, 1.0, table, n); n += 1
                 continue
             if op == "edit":
                 r = int(rng.integers(n)); X[r] = lorentz_table(1, d, seed=int(rng.integers(1 << 30)), scale=0.05).numpy()[0]
@@ -47,6 +55,14 @@ for t in range(seqs):
             if op == "topk":
                 dd, ii, jj, cnt = eng.topk(1.0, thr, 50, r0, r1)
                 ok = cnt == oc and np.array_equal(ii, oi) and np.array_equal(jj, oj) and np.array_equal(dd.view(np.uint32), od.view(np.uint32))
+            elif op in ("topk_nc", "refresh"):          # the uncounted refresh (incremental where it applies), whole or in two halves
+                out = None
+                if op == "refresh" and eng.topk_refresh_begin(1.0, thr, 50):
+                    out = eng.topk_refresh_end()
+                if out is None:
+                    out = eng.topk(1.0, thr, 50, count=False)[:3]
+                dd, ii, jj = out
+                ok = np.array_equal(ii, oi) and np.array_equal(jj, oj) and np.array_equal(dd.view(np.uint32), od.view(np.uint32))
             elif op == "dev":
                 eng.argmin_into(1.0, thr, r0, r1, rec); g = rec.cpu().numpy()
                 got = None if g[0] == 0 else (int(np.uint32(g[1])), int(g[2]), int(g[3]))
