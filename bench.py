@@ -124,6 +124,7 @@ def std_loop_leg(vocab_size, dim, prefilter, sign, steps, device, thr=THR, label
                               max_vocab_size=vocab_size + steps + 80, sign_convention=sign, prefilter=prefilter)
     eng = tok._get_engine()
     tok.optimize_merges(steps=8, log_every=10 ** 9)
+    eng.debug_time_loops(True)                   # every scan of the timed loop carries its event pair (in the dispatch)
     eng.scan_totals(reset=True)
     gc.collect()
     torch.cuda.synchronize()
@@ -133,6 +134,7 @@ def std_loop_leg(vocab_size, dim, prefilter, sign, steps, device, thr=THR, label
     el = time.perf_counter() - t0
     done = len(tok.merge_history) - 8
     tot = eng.scan_totals()
+    eng.debug_time_loops(False)
     out = {"workload": label, "merges_per_s": done / el if el > 0 else None, "ms_per_step": 1e3 * el / max(done, 1), "steps": done}
     if tot["launches"] > 0 and tot["scan_ms"] > 0:
         ms = tot["scan_ms"] / tot["launches"]
