@@ -409,6 +409,7 @@ def main() -> None:
     tok = HyperbolicTokenizer(vocab, torch.nn.Parameter(X), curvature=CURV, merge_threshold=THR, device=device,
                               max_vocab_size=V + steps_total + 192, sign_convention="lorentz", shard=shard)
     eng = tok._get_engine()                      # builds the scan image: inputs resident before timing
+    tok._sync_token_lengths(eng)                 # (the token lengths the device-resident loop reads are inputs too)
     torch.cuda.synchronize()
 
     def barrier():

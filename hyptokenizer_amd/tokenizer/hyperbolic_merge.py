@@ -322,7 +322,7 @@ class HyperbolicTokenizer:
     def _sync_token_lengths(self, eng) -> None:
         n = self.current_vocab_size
         if self._len_state != (id(eng), n):
-            eng.set_token_lengths([len(t) for t in self.vocab[:n]])
+            eng.set_token_lengths(np.fromiter(map(len, self.vocab[:n]), dtype=np.int32, count=n))
             self._len_state = (id(eng), n)
 
     def _device_steps(self, count: int):
