@@ -419,16 +419,20 @@ def main() -> None:
     torch.cuda.synchronize()
 
     def barrier():
-        # a generation-2 collection over three 50k-token vocabularies is a 50 ms host stall: collect between the
-        # legs and park the survivors, so that no leg's clock is charged for it
-        gc.collect()
-        gc.freeze()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def settle():
+        # a generation-2 collection over three 50k-token vocabularies is a 50 ms host stall: collect between the legs and
+        # park the survivors -- BEFORE the clocks are warmed, never between the warm-up and a timed region (the GPU idles
+        # for the duration and the timed region then starts on cold clocks: its first hundred scans ran 5-15 % slower)
+        gc.collect()
+        gc.freeze()
+
     tok.optimize_merges(steps=args.warmup, log_every=10 ** 9)
+    settle()
     if world == 1:
         warm_clocks(eng)                         # >= 60 ms of scans whatever --warmup says
     # Every scan launch of the timed region carries its own HIP event pair IN the dispatch (start / stop timestamps of that
@@ -470,6 +474,7 @@ def main() -> None:
                                        max_vocab_size=V + fsteps + 64, sign_convention="lorentz", shard=shard)
         ftok._get_engine()
         ftok.optimize_merges(steps=202, log_every=10 ** 9, adaptive_threshold=False)
+        settle()
         barrier()
         tf0 = time.perf_counter()
         ftok.optimize_merges(steps=fsteps - 202, log_every=10 ** 9, adaptive_threshold=False)
@@ -489,6 +494,7 @@ def main() -> None:
                                    max_vocab_size=V + isteps + 64, sign_convention="lorentz", shard=shard, incremental=True)
         itok._get_engine()
         itok.optimize_merges(steps=1, log_every=10 ** 9)           # the one full search
+        settle()
         barrier()
         ti0 = time.perf_counter()
         itok.optimize_merges(steps=isteps - 1, log_every=10 ** 9)
@@ -520,6 +526,7 @@ def main() -> None:
                 legs[key] = fn()
             except Exception as exc:             # a leg must not take the headline line down with it
                 legs[key] = {"error": f"{type(exc).__name__}: {exc}"}
+            settle()
             barrier()
         try:
             bw = bandwidth_kernels(device)

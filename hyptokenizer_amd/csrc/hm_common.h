@@ -202,6 +202,10 @@ struct hm_engine {
     std::vector<hipEvent_t> loop_evs;     // 2 * HM_LOOP_MAX_STEPS + 2, created on first use
     float last_batch_ms = 0.f, last_batch_scan_ms = 0.f;
     int64_t last_batch_steps = 0;
+    // the event pairs of the last complete batch are read when somebody asks (hm_scan_totals, hm_last_loop_timing) or
+    // when the next batch needs the events -- not inside the call a benchmark is timing
+    int64_t loop_unread_steps = 0;
+    std::vector<int64_t> loop_unread_pairs;
     // stats
     float last_scan_ms = 0.f;
     int64_t last_pairs = 0, last_emitted = 0;
@@ -241,6 +245,7 @@ hipError_t hm_launch_scan(hm_engine* e, int mode, const ScanArgs& a, dim3 grid, 
                           hipEvent_t ev1 = nullptr);
 int64_t hm_pairs_in_range(int64_t n, int64_t r0, int64_t r1);
 void hm_flush_pending_timing(hm_engine* e);
+void hm_read_loop_events(hm_engine* e);
 
 // ---- hm_rows.hip ----
 int hm_build_rows(hm_engine* e, const float* X, int64_t ld, int64_t r0, int64_t r1, hipStream_t s);

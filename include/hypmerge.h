@@ -200,7 +200,7 @@ int hm_shard_loop_end(hm_engine* e, int64_t steps, uint32_t* rec_out, int64_t* d
  * them enter hm_scan_totals) and around the whole batch; hm_last_loop_timing returns the last batch's wall time on the
  * device, the sum of its scan launches and its step count (0 when the batch stopped early). */
 int hm_debug_time_loops(hm_engine* e, int on);
-int hm_last_loop_timing(const hm_engine* e, float* batch_ms, float* scan_ms, int64_t* steps);
+int hm_last_loop_timing(hm_engine* e, float* batch_ms, float* scan_ms, int64_t* steps);
 
 /* ---- enhanced tokenizer (BASELINE config 5) ---------------------------------------------------------------
  * Semantic-coherence distances: for candidate t the simulated merged embedding
