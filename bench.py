@@ -107,11 +107,11 @@ def traffic_from_profiles(form: str):
         return None, None
 
 
-def warm_clocks(eng, ms: float = 60.0) -> None:
+def warm_clocks(eng, ms: float = 60.0, thr: float = THR) -> None:
     """>= `ms` of back-to-back scans before a timed region: a 20-step run must measure the steady state"""
     t0 = time.perf_counter()
     while (time.perf_counter() - t0) * 1e3 < ms:
-        eng.argmin(CURV, THR)
+        eng.argmin(CURV, thr)
     torch.cuda.synchronize()
 
 
@@ -124,9 +124,10 @@ def std_loop_leg(vocab_size, dim, prefilter, sign, steps, device, thr=THR, label
                               max_vocab_size=vocab_size + steps + 80, sign_convention=sign, prefilter=prefilter)
     eng = tok._get_engine()
     tok.optimize_merges(steps=8, log_every=10 ** 9)
+    gc.collect()                                 # (before the warm-up, not between it and the timed loop)
+    warm_clocks(eng, 40.0, thr)
     eng.debug_time_loops(True)                   # every scan of the timed loop carries its event pair (in the dispatch)
     eng.scan_totals(reset=True)
-    gc.collect()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tok.optimize_merges(steps=steps, log_every=10 ** 9)
