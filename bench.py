@@ -436,6 +436,13 @@ def main() -> None:
     settle()
     if world == 1:
         warm_clocks(eng)                         # >= 60 ms of scans whatever --warmup says
+    else:
+        # the same for the sharded run: a FIXED number of global searches (a time-based loop would let the ranks disagree
+        # on the number of collectives)
+        from hyptokenizer_amd.sharding import sharded_argmin
+        for _ in range(200):
+            sharded_argmin(eng, shard, CURV, tok._search_threshold())
+        torch.cuda.synchronize()
     # Every scan launch of the timed region carries its own HIP event pair IN the dispatch (start / stop timestamps of that
     # kernel: no extra packets on the stream), and each device batch one pair around it: the roofline's mean launch duration
     # and the time a step spends outside the scan both come from the timed region itself.
