@@ -391,14 +391,23 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the merge engine has no CPU fallback")
+    # HM_BENCH_REHEARSE=1: the N > 1 code path on a box with ONE GPU -- every rank uses cuda:0 and the exchange goes over
+    # gloo (CPU tensors).  Only for checking that the path runs; its numbers mean nothing.
+    rehearse = os.environ.get("HM_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    xdev = torch.device("cpu") if rehearse else device          # where the bench's own small collectives live
     shard = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         from hyptokenizer_amd.sharding import ShardContext
-        shard = ShardContext(device=device)
+        shard = ShardContext(device=xdev)
 
     from hyptokenizer_amd.synthetic import cjk_vocab, lorentz_table
     from hyptokenizer_amd.tokenizer.fast_hyperbolic_merge import FastHyperbolicTokenizer
@@ -464,10 +473,10 @@ def main() -> None:
         if lt["steps"] > 0:
             loop_t = lt
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        agg = torch.tensor([tot["scan_ms"], float(tot["pairs"]), float(tot["launches"])], dtype=torch.float64, device=device)
+        agg = torch.tensor([tot["scan_ms"], float(tot["pairs"]), float(tot["launches"])], dtype=torch.float64, device=xdev)
         lst = [torch.zeros_like(agg) for _ in range(world)]
         dist.all_gather(lst, agg)
         per_rank = [x.cpu().tolist() for x in lst]

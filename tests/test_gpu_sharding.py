@@ -187,3 +187,26 @@ def test_device_merge_of_gathered_topk_lists_matches_lexsort():
     d, i, j, tot = merge_topk_lists_device(torch.from_numpy(buf).cuda(), k)
     assert tot == total
     assert np.array_equal(d.view(np.uint32), du[order]) and np.array_equal(i, ii[order]) and np.array_equal(j, jj[order])
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """``bench.py --gpus 2`` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE GPU:
+    HM_BENCH_REHEARSE=1 puts both ranks on cuda:0 and the exchange on gloo.  Checks that the N > 1 path of the bench runs end
+    to end -- rendezvous, sharded device loop, sharded fast and incremental loops, the bench's own collectives, one JSON line
+    from rank 0 -- and that the sharded incremental loop merges what the sharded full search merges."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HM_BENCH_REHEARSE="1", TQDM_DISABLE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--no-legs", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["incremental"]["same_merges_as_full_search"] is True and d["fast_path"]["merges_per_s"] > 0
