@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "hm_merge_append_batch", "hm_truncate", "hm_set_token_lengths", "hm_std_merge_steps", "hm_incr_merge_steps",
     "hm_coherence_batch", "hm_project_table", "hm_debug_force_cut", "hm_randperm_prefix", "hm_merge_append_batch_host",
     "hm_tokenize_table_capacity", "hm_tokenize_build_table", "hm_tokenize_batch", "hm_debug_time_loops", "hm_last_loop_timing", "hm_shard_loop_begin", "hm_shard_merge_step", "hm_shard_loop_end",
-    "hm_topk_refresh_begin", "hm_topk_refresh_end",
+    "hm_topk_refresh_begin", "hm_topk_refresh_end", "hm_debug_set_knob", "hm_debug_set_default_knob",
 )
 
 
@@ -98,6 +98,8 @@ def load() -> C.CDLL:
     L.hm_tokenize_table_capacity.argtypes = [i64]
     L.hm_tokenize_build_table.argtypes = [vp, vp, vp, i64, vp, i64]
     L.hm_tokenize_batch.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp]
+    L.hm_debug_set_knob.argtypes = [vp, C.c_char_p, C.c_double]
+    L.hm_debug_set_default_knob.argtypes = [C.c_char_p, C.c_double, C.c_int]
     L.hm_engine_destroy.argtypes = [vp]
     L.hm_set_table.argtypes = [vp, vp, i64, i64, vp]
     L.hm_update_rows.argtypes = [vp, vp, i64, i64, i64, vp]
@@ -122,7 +124,7 @@ def load() -> C.CDLL:
     L.hm_scan_totals.argtypes = [vp, C.POINTER(C.c_double), pi64, pi64, C.c_int]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("hm_last_error", "hm_rows"):
+        if name not in ("hm_last_error", "hm_rows", "hm_tokenize_table_capacity"):
             fn.restype = C.c_int
     _lib = L
     return L

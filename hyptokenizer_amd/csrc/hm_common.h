@@ -10,10 +10,12 @@
 // make the 16-byte chunks per row odd), NG = groups of 4 spatial coordinates.  Group g holds spatial
 // coordinates s = 4g..4g+3 in the order [s0, s2, s1, s3] so that lane-half h of a wave reads ONE
 // 8-byte word (position 2h) holding its operands for the two MFMA k-steps of the group; the time
-// chunk [x0, 0, 0, 0] is last.  The bf16 image img16[rows_alloc][32*KS + 16 bytes]: KS k-steps of 16
-// bf16 (spatial coordinates, then the time coordinate split hi + lo in the last four slots) and a
-// trailing chunk [x0 fp32, 0, 0, 0] (odd chunk count: conflict-free ds_read_b128).  A 64-row tile of
-// either image is one contiguous block -> LDS-DMA in 1 KiB pieces, no padding.
+// chunk [x0, 0, 0, 0] is last.  The bf16 image img16[rows_alloc][16 * hm_row16_chunks(KC) bytes]: KC chunks of
+// 8 K-slots as bf16 (spatial coordinates, then the time coordinate split hi + lo in the last four slots of the
+// last chunk) and, when KC is even, a trailing chunk [x0 fp32, 0, 0, 0] (odd chunk count: conflict-free
+// ds_read_b128).  A k-step of the MFMA is two chunks; an odd KC ends on a half step (v_mfma_f32_32x32x8_bf16_1k):
+// d = 100 needs 104 slots = 13 chunks = 208 bytes per row.  A 64-row tile of either image is one contiguous
+// block -> LDS-DMA in 1 KiB pieces, no padding.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -63,6 +65,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // floats per fp32 image row
 __host__ __device__ constexpr int hm_row_floats(int NG) { return 4 * NG + 4 + (((NG + 1) % 2 == 0) ? 4 : 0); }
+// 16-byte chunks per bf16 image row: KC chunks of 8 K-slots (+ the [x0] chunk that makes an even count odd)
+__host__ __device__ constexpr int hm_row16_chunks(int KC) { return KC + ((KC & 1) ? 0 : 1); }
 __device__ __forceinline__ int hm_pos_in_group(int s) { return ((s & 1) << 1) | ((s >> 1) & 1); }  // 0,2,1,3
 // offset of spatial coordinate s inside an fp32 image row
 __device__ __forceinline__ int hm_img_off(int s) { return 4 * (s >> 2) + hm_pos_in_group(s & 3); }
@@ -97,10 +101,13 @@ struct ScanArgs {
     int sample_stride;
     const uint32_t* rmax2_bits;   // [0] largest squared row norm, [1] largest squared spatial norm (float bits)
     const uint32_t* stop;         // device-resident loops: a non-zero word makes every block return at once (may be NULL)
-    // persistent work distribution (TOPK / ARGMIN launches): the launch's tiles form one row-major sequence of p_total
-    // tiles over n_rb row blocks; a resident grid walks equal shares of it
-    int persist, n_rb;
-    long long p_total;
+    // XCD-sliced unit queues (large TOPK / ARGMIN launches, hm_scan.hip): n_rb row blocks from rb_first on, one unit per
+    // (row block, slice of the column tiles); xq_heads = 9 counters on 128-byte lines (8 queue heads + blocks gone)
+    int xq, n_rb;
+    uint32_t* xq_heads;
+#if defined(HM_DIAG_STAMPS)
+    unsigned long long* diag;     // diagnostic builds: per-phase cycle sums (hm_scan.hip)
+#endif
 };
 
 // Seed of the argmin search's running key, kept on the device between searches: the key of the last
@@ -137,7 +144,8 @@ struct hm_engine {
     // work-decomposition knobs (HM_TUNE_* environment overrides are a tuning aid)
     int chunk_f32 = 32, chunk_bf16 = 96, tail_div = 4;
     double tail_fraction = 0.20;
-    int persist = 0;                      // HM_TUNE_PERSIST=1: resident grid walking equal shares of the tile sequence (experiment: slower)
+    int64_t xq_min_pairs = 0;             // launches covering at least this many pairs use the XCD-sliced unit queues (0: never; experiment)
+    uint32_t* d_xq = nullptr;             // their 9 counters (zero between launches: the kernel's last block re-zeroes them)
     std::map<const void*, int> occupancy;  // resident blocks per CU of each scan kernel
     int force_shape = -1;                 // HM_TUNE_SHAPE: bf16 block shape of every launch (tuning builds)
     int64_t big_min_rows = 80000;         // bf16 form: launches covering at least the pairs of this many rows use 512-row blocks
@@ -145,7 +153,7 @@ struct hm_engine {
     int d1 = 0, d = 0, NG = 0, RS = 0, sign_mode = 0;
     float* img = nullptr;
     unsigned char* img16 = nullptr;
-    int KS = 0, RB16 = 0;                 // k-steps of 16 and bytes per bf16 image row
+    int KC = 0, RB16 = 0;                 // chunks of 8 K-slots and bytes per bf16 image row
     int precision = HM_PREFILTER_AUTO;
     bool bf16_ok = true;                  // false: no bf16 image for this width (d > 124)
     uint4* ent = nullptr;
@@ -427,12 +435,12 @@ __device__ __forceinline__ uint32_t hm_pack_bf16(float lo, float hi)
 // chunk c (K-slots 8c .. 8c+7) of a bf16 image row; the LAST FOUR slots of the row hold the time coordinate
 // split as x0 ~ hi + lo: streamed (B) encoding [hi, lo, hi, 0]; the stationary (A) side rewrites its copy in
 // registers to [-hi, -hi, -lo, 0], so the MFMA adds -(hi*hi' + hi*lo' + lo*hi') = -x0*y0 (1 + O(2^-16)).
-__device__ __forceinline__ uint4 hm_bf16_chunk(const float* spatial /* x[1..d] */, float x0, int d, int KS, int c)
+__device__ __forceinline__ uint4 hm_bf16_chunk(const float* spatial /* x[1..d] */, float x0, int d, int KC, int c)
 {
     float f[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const int sidx = 8 * c + q; f[q] = sidx < d ? spatial[sidx] : 0.0f; }
-    if (c == 2 * KS - 1) {
+    if (c == KC - 1) {
         const __bf16 hb = (__bf16)x0;
         const float hi = (float)hb;
         const float lo = x0 - hi;

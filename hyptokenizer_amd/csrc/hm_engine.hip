@@ -18,12 +18,12 @@ int hm_fail(hm_engine* e, int code, const std::string& msg)
 }
 
 static const int kSupportedNG[] = {1, 2, 3, 4, 6, 8, 10, 13, 16, 20, 25, 28, 32};
-static const int kSupportedKS[] = {1, 2, 4, 7, 8};      // bf16 form: 16 K-slots per k-step
+static const int kSupportedKC[] = {2, 4, 8, 13, 14, 16};   // bf16 form: chunks of 8 K-slots (two per k-step; 13 ends on a half step)
 
-static int hm_pick_ks(int d)
+static int hm_pick_kc(int d)
 {
-    const int need = (d + 4 + 15) / 16;        // d spatial slots + 4 slots for the split time coordinate
-    for (int v : kSupportedKS)
+    const int need = (d + 4 + 7) / 8;          // d spatial slots + 4 slots for the split time coordinate
+    for (int v : kSupportedKC)
         if (v >= need) return v;
     return -1;
 }
@@ -37,6 +37,60 @@ static int hm_pick_ng(int d)
 }
 
 extern "C" int hm_abi_version(void) { return HM_ABI_VERSION; }
+
+// ---- work-decomposition knobs (test / tuning hook: hm_debug_set_knob, hm_debug_set_default_knob) ----
+static const char* const kKnobNames[] = {"chunk", "tail", "tail_div", "big_rows", "shape", "incr_topk", "xq_pairs", "kc_even"};
+static std::map<std::string, double> g_default_knobs;          // applied to every engine created afterwards
+
+static int hm_apply_knob(hm_engine* e, const char* name, double v)
+{
+    const std::string k = name ? name : "";
+    if (k == "chunk") { if (!(v >= 4 && v <= 4096)) return HM_E_ARG; e->chunk_f32 = e->chunk_bf16 = (int)v; }
+    else if (k == "tail") { if (!(v >= 0.0 && v <= 0.9)) return HM_E_ARG; e->tail_fraction = v; }
+    else if (k == "tail_div") { if (!(v >= 1 && v <= 16)) return HM_E_ARG; e->tail_div = (int)v; }
+    else if (k == "big_rows") { if (!(v >= 0)) return HM_E_ARG; e->big_min_rows = (int64_t)v; }          // 512-row blocks from this many rows' pairs on
+    else if (k == "shape") { if (!(v >= -1 && v <= 4)) return HM_E_ARG; e->force_shape = (int)v; }
+    else if (k == "incr_topk") e->incremental_topk = v != 0.0;
+    else if (k == "xq_pairs") { if (!(v >= 0)) return HM_E_ARG; e->xq_min_pairs = (int64_t)v; }          // XCD-sliced queues from this many pairs on (0: never)
+    else if (k == "kc_even") {            // bf16 image with an even chunk count (whole k-steps only): default knob only, before the images exist
+        if (e->img16 != nullptr) return HM_E_STATE;
+        if (v != 0.0 && (e->KC & 1)) { e->KC += 1; e->RB16 = 16 * hm_row16_chunks(e->KC); }
+    }
+    else return HM_E_ARG;
+    e->armed = false;
+    return HM_OK;
+}
+
+extern "C" int hm_debug_set_knob(hm_engine* e, const char* name, double value)
+{
+    if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_debug_set_knob: engine is NULL");
+    const int rc = hm_apply_knob(e, name, value);
+    return rc ? hm_fail(e, rc, "hm_debug_set_knob: unknown knob or value out of range") : HM_OK;
+}
+
+#if defined(HM_DIAG_STAMPS)
+// diagnostic builds: read (and clear) the per-phase cycle sums of the scans since the last call
+extern "C" int hm_diag_read(hm_engine* e, unsigned long long* out, int with_blocks)
+{
+    HM_HIP(hipSetDevice(e->device));
+    HM_HIP(hipDeviceSynchronize());
+    const size_t n = with_blocks ? (16 + 4 * 8192 + 8 * 4096) : 16;
+    HM_HIP(hipMemcpy(out, e->d_xq + 32 * 9, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HM_HIP(hipMemset(e->d_xq + 32 * 9, 0, (16 + 4 * 8192 + 8 * 4096) * sizeof(unsigned long long)));
+    return HM_OK;
+}
+#endif
+
+extern "C" int hm_debug_set_default_knob(const char* name, double value, int clear)
+{
+    const std::string k = name ? name : "";
+    if (clear) { if (k.empty()) g_default_knobs.clear(); else g_default_knobs.erase(k); return HM_OK; }
+    hm_engine probe;
+    const int rc = hm_apply_knob(&probe, name, value);
+    if (rc) return hm_fail(nullptr, rc, "hm_debug_set_default_knob: unknown knob or value out of range");
+    g_default_knobs[k] = value;
+    return HM_OK;
+}
 
 extern "C" const char* hm_last_error(const hm_engine* e)
 {
@@ -69,6 +123,13 @@ static int hm_engine_alloc(hm_engine* e)
     HM_HIP(hipMemset(e->d_rmax2, 0, sizeof(uint32_t) * 2));
     HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 4));
     HM_HIP(hipMemset(e->d_ctr64, 0, sizeof(unsigned long long) * 4));
+#if defined(HM_DIAG_STAMPS)
+    const size_t diag_bytes = (16 + 4 * 8192 + 8 * 4096) * sizeof(unsigned long long);      // phase sums + per-block stamps + unit log
+#else
+    const size_t diag_bytes = 0;
+#endif
+    HM_HIP(hipMalloc(&e->d_xq, sizeof(uint32_t) * 32 * 9 + diag_bytes));
+    HM_HIP(hipMemset(e->d_xq, 0, sizeof(uint32_t) * 32 * 9 + diag_bytes));
     HM_HIP(hipMalloc(&e->d_seed, sizeof(ArgminSeed)));
     HM_HIP(hipMemset(e->d_seed, 0, sizeof(ArgminSeed)));
     HM_HIP(hipMalloc(&e->d_rec, 2 * sizeof(ArgminRec)));
@@ -111,25 +172,27 @@ extern "C" int hm_engine_create(hm_engine** out, int device, int64_t max_rows, i
     e->RS = hm_row_floats(e->NG);
     e->sign_mode = sign_mode;
     e->rows_alloc = (max_rows + HM_MAX_BLOCK_ROWS - 1) / HM_MAX_BLOCK_ROWS * HM_MAX_BLOCK_ROWS + HM_MAX_BLOCK_ROWS;
-    e->KS = hm_pick_ks(e->d);
-    if (e->KS < 0) {                     // d > 124: the k-steps instantiated do not hold d + 4 slots -- fp32 form only
-        e->KS = 0;                       // (the bf16 image degenerates to its [x0] chunk)
+    e->KC = hm_pick_kc(e->d);
+    if (e->KC < 0) {                     // d > 124: the k-steps instantiated do not hold d + 4 slots -- fp32 form only
+        e->KC = 0;                       // (the bf16 image degenerates to its [x0] chunk)
         e->bf16_ok = false;
     }
-    e->RB16 = 32 * e->KS + 16;
+    e->RB16 = 16 * hm_row16_chunks(e->KC);
     e->precision = prefilter;
     if (const char* pe = getenv("HM_SCAN_PRECISION")) {       // override of the argument: "f32" | "bf16"
         if (!strcmp(pe, "f32")) e->precision = HM_PREFILTER_F32;
         else if (!strcmp(pe, "bf16")) e->precision = HM_PREFILTER_BF16;
     }
-    if (const char* t = getenv("HM_TUNE_CHUNK")) { const int v = atoi(t); if (v >= 4 && v <= 4096) e->chunk_f32 = e->chunk_bf16 = v; }
-    if (const char* t = getenv("HM_TUNE_TAIL")) { const double v = atof(t); if (v >= 0.0 && v <= 0.9) e->tail_fraction = v; }
-    if (const char* t = getenv("HM_TUNE_BIG_ROWS")) { const long v = atol(t); if (v >= 0) e->big_min_rows = v; }
-    else if (const char* t2 = getenv("HM_TUNE_TM4_ROWS")) { const long v = atol(t2); if (v >= 0) e->big_min_rows = v; }   // round-1 name
-    if (const char* t = getenv("HM_TUNE_INCR_TOPK")) e->incremental_topk = atoi(t) != 0;
-    if (const char* t = getenv("HM_TUNE_PERSIST")) { const int v = atoi(t); if (v >= 0 && v <= 9) e->persist = v; }
-    if (const char* t = getenv("HM_TUNE_SHAPE")) { const int v = atoi(t); if (v >= 0 && v <= 4) e->force_shape = v; }
-    if (const char* t = getenv("HM_TUNE_TAIL_DIV")) { const int v = atoi(t); if (v >= 1 && v <= 16) e->tail_div = v; }
+    for (const auto& kv : g_default_knobs) (void)hm_apply_knob(e, kv.first.c_str(), kv.second);
+#if defined(HM_TUNING)
+    // tuning builds (tools/build_variant.sh adds -DHM_TUNING) also take the knobs from the environment, HM_TUNE_<NAME>;
+    // the shipped library reads no such variable
+    for (const char* name : kKnobNames) {
+        std::string var = "HM_TUNE_";
+        for (const char* q = name; *q; ++q) var += (char)toupper(*q);
+        if (const char* t = getenv(var.c_str())) (void)hm_apply_knob(e, name, atof(t));
+    }
+#endif
     // emission buffers: every pair of the largest table when that is small, 2^24 entries (256 MiB) at most
     {
         const uint64_t pairs = (uint64_t)max_rows * (uint64_t)(max_rows - 1) / 2;
@@ -153,7 +216,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
     void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts,
-                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch};
+                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch, e->d_xq};
     for (void* q : dev_ptrs)
         if (q) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);

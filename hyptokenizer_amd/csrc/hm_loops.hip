@@ -149,7 +149,7 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
 struct IncrArgs {
     float* img;
     unsigned char* img16;
-    int RS, d, KS, sign_mode;
+    int RS, d, KC, sign_mode;
     float c, sqrt_c, thr;
     float* X;
     int64_t ld;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64 * HM_INCR_WAVES) void hm_incr_step_kernel(const 
         hm_wave_stage_rows(a.img, a.RS, a.d, best.i, best.j, ms, lane);
         const float r2 = hm_wave_midpoint(a.d, w, a.c, a.sign_mode, ms, true, lane);
         if (blockIdx.x == 0) {
-            hm_wave_store_row(ms, r2, a.d, a.RS, a.KS, a.X, a.ld, a.img, a.img16, a.new_row, a.rmax2_bits, lane);
+            hm_wave_store_row(ms, r2, a.d, a.RS, a.KC, a.X, a.ld, a.img, a.img16, a.new_row, a.rmax2_bits, lane);
             if (lane == 0) {
                 a.len[a.new_row] = li + lj;
                 *a.rec_ring = best;                        // the pair this step merged
@@ -260,7 +260,7 @@ extern "C" int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_de
     HM_HIP(hipMemsetAsync(e->d_loop->rowkey, 0xff, sizeof(unsigned long long) * HM_LOOP_MAX_STEPS, s));
     HM_HIP(hipMemcpyAsync(&e->d_loop->best, &e->h->rec2[0], sizeof(ArgminRec), hipMemcpyHostToDevice, s));
     IncrArgs a;
-    a.img = e->img; a.img16 = e->img16; a.RS = e->RS; a.d = e->d; a.KS = e->KS; a.sign_mode = e->sign_mode;
+    a.img = e->img; a.img16 = e->img16; a.RS = e->RS; a.d = e->d; a.KC = e->KC; a.sign_mode = e->sign_mode;
     a.c = c; a.sqrt_c = sqrtf(c); a.thr = thr; a.X = X_dev; a.ld = ld; a.len = e->d_len; a.loop = e->d_loop;
     a.rmax2_bits = e->d_rmax2;
     const size_t lds = sizeof(float) * (size_t)HM_INCR_WAVES * HM_TILE_ROWS * e->RS;
@@ -313,7 +313,7 @@ struct ShardMergeArgs {
     int world;
     float* img;
     unsigned char* img16;
-    int RS, d, KS, sign_mode;
+    int RS, d, KC, sign_mode;
     float c;
     float* X;
     int64_t ld;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64) void hm_shard_merge_kernel(const ShardMergeArgs
     const float w = (float)((double)lj / (double)(li + lj));
     hm_wave_stage_rows(a.img, a.RS, a.d, b1, b2, ms, lane);
     const float r2 = hm_wave_midpoint(a.d, w, a.c, a.sign_mode, ms, true, lane);
-    hm_wave_store_row(ms, r2, a.d, a.RS, a.KS, a.X, a.ld, a.img, a.img16, a.new_row, a.rmax2_bits, lane);
+    hm_wave_store_row(ms, r2, a.d, a.RS, a.KC, a.X, a.ld, a.img, a.img16, a.new_row, a.rmax2_bits, lane);
     if (lane == 0) {
         a.len[a.new_row] = li + lj;
         ArgminRec r; r.found = 1u; r.dbits = b0; r.i = b1; r.j = b2;
@@ -389,7 +389,7 @@ extern "C" int hm_shard_merge_step(hm_engine* e, const uint32_t* recs_dev, int w
     HM_HIP(hipSetDevice(e->device));
     ShardMergeArgs a;
     a.recs = reinterpret_cast<const ArgminRec*>(recs_dev); a.world = world;
-    a.img = e->img; a.img16 = e->img16; a.RS = e->RS; a.d = e->d; a.KS = e->KS; a.sign_mode = e->sign_mode;
+    a.img = e->img; a.img16 = e->img16; a.RS = e->RS; a.d = e->d; a.KC = e->KC; a.sign_mode = e->sign_mode;
     a.c = c; a.X = X_dev; a.ld = ld; a.new_row = e->n; a.len = e->d_len; a.loop = e->d_loop;
     a.rec_ring = e->d_loop_recs + step; a.rmax2_bits = e->d_rmax2;
     hipLaunchKernelGGL(hm_shard_merge_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);

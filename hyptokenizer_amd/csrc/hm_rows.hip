@@ -56,21 +56,21 @@ __global__ void hm_rownorm_kernel(const float* __restrict__ img, int RS, int64_t
     }
 }
 
-// bf16 image row: KS x 16 K-slots as bf16 (round to nearest even) followed by one 16-byte chunk
-// [x0 as fp32, 0, 0, 0] (2*KS + 1 chunks per row: always odd, so the ds_read_b128 fragment reads of
+// bf16 image row: KC chunks of 8 K-slots as bf16 (round to nearest even), followed -- when KC is even -- by one
+// 16-byte chunk [x0 as fp32, 0, 0, 0] (chunks per row: always odd, so the ds_read_b128 fragment reads of
 // 32 consecutive rows fall on distinct 16-byte bank slots).
-__global__ void hm_build_image16_kernel(const float* __restrict__ X, int64_t ld, int d, int KS, unsigned char* __restrict__ img16,
+__global__ void hm_build_image16_kernel(const float* __restrict__ X, int64_t ld, int d, int KC, unsigned char* __restrict__ img16,
                                         int64_t row_begin, int64_t row_end)
 {
-    const int CH = 2 * KS + 1;                        // 16-byte chunks per row
+    const int CH = hm_row16_chunks(KC);               // 16-byte chunks per row
     const int64_t total = (row_end - row_begin) * CH;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = row_begin + t / CH;
         const int c = (int)(t % CH);
         uint4 v = make_uint4(0, 0, 0, 0);
         const float* xr = X + row * ld;
-        if (c == CH - 1) v.x = hm::fbits(xr[0]);
-        else v = hm_bf16_chunk(xr + 1, xr[0], d, KS, c);
+        if (c >= KC) v.x = hm::fbits(xr[0]);
+        else v = hm_bf16_chunk(xr + 1, xr[0], d, KC, c);
         *reinterpret_cast<uint4*>(img16 + (row * CH + c) * 16) = v;
     }
 }
@@ -84,9 +84,9 @@ int hm_build_rows(hm_engine* e, const float* X, int64_t ld, int64_t r0, int64_t 
     HM_HIP(hipGetLastError());
     hipLaunchKernelGGL(hm_rownorm_kernel, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, s, e->img, e->RS, r0, r1, e->d_rmax2);
     HM_HIP(hipGetLastError());
-    const int64_t total16 = (r1 - r0) * (2 * e->KS + 1);
+    const int64_t total16 = (r1 - r0) * hm_row16_chunks(e->KC);
     hipLaunchKernelGGL(hm_build_image16_kernel, dim3((unsigned)std::min<int64_t>((total16 + 255) / 256, 4096)), dim3(256), 0, s, X, ld,
-                       e->d, e->KS, e->img16, r0, r1);
+                       e->d, e->KC, e->img16, r0, r1);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
@@ -164,13 +164,13 @@ __global__ __launch_bounds__(256) void hm_midpoint_kernel(const float* __restric
 // fused merge: midpoint of image rows (i, j) -> table row and image rows `new_row` (hyperbolic_merge.py:326-351)
 __global__ __launch_bounds__(64) void hm_merge_append_kernel(float* __restrict__ img, int RS, int d, int32_t i, int32_t j, float w, float c,
                                                              int sign_mode, float* __restrict__ X, int64_t ld, int64_t new_row,
-                                                             uint32_t* __restrict__ rmax2_bits, unsigned char* __restrict__ img16, int KS)
+                                                             uint32_t* __restrict__ rmax2_bits, unsigned char* __restrict__ img16, int KC)
 {
     __shared__ MidScratch ms;
     const int lane = threadIdx.x;
     hm_wave_stage_rows(img, RS, d, i, j, ms, lane);
     const float r2 = hm_wave_midpoint(d, w, c, sign_mode, ms, true, lane);
-    hm_wave_store_row(ms, r2, d, RS, KS, X, ld, img, img16, new_row, rmax2_bits, lane);
+    hm_wave_store_row(ms, r2, d, RS, KC, X, ld, img, img16, new_row, rmax2_bits, lane);
 }
 
 // several merges known in advance (the fast tokenizer knows every merge between two refreshes when the refresh
@@ -179,14 +179,14 @@ __global__ __launch_bounds__(64) void hm_merge_append_kernel(float* __restrict__
 __global__ __launch_bounds__(64) void hm_merge_batch_kernel(float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
                                                             const int32_t* __restrict__ J, const float* __restrict__ W, int count, float c,
                                                             int sign_mode, float* __restrict__ X, int64_t ld, int64_t first_row,
-                                                            uint32_t* __restrict__ rmax2_bits, unsigned char* __restrict__ img16, int KS)
+                                                            uint32_t* __restrict__ rmax2_bits, unsigned char* __restrict__ img16, int KC)
 {
     __shared__ MidScratch ms;
     const int lane = threadIdx.x;
     for (int t = 0; t < count; ++t) {
         hm_wave_stage_rows(img, RS, d, I[t], J[t], ms, lane);
         const float r2 = hm_wave_midpoint(d, W[t], c, sign_mode, ms, true, lane);
-        hm_wave_store_row(ms, r2, d, RS, KS, X, ld, img, img16, first_row + t, rmax2_bits, lane);
+        hm_wave_store_row(ms, r2, d, RS, KC, X, ld, img, img16, first_row + t, rmax2_bits, lane);
         __threadfence();                                      // the next merge of the batch may read this row
         hm_wave_lds_sync();
     }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void hm_merge_batch_kernel(float* __restrict__ 
 __global__ __launch_bounds__(256) void hm_merge_rows_kernel(float* __restrict__ img, int RS, int d, const int32_t* __restrict__ I,
                                                             const int32_t* __restrict__ J, const float* __restrict__ W, int count, float c,
                                                             int sign_mode, float* __restrict__ X, int64_t ld, int64_t first_row,
-                                                            uint32_t* __restrict__ rmax2_bits, unsigned char* __restrict__ img16, int KS)
+                                                            uint32_t* __restrict__ rmax2_bits, unsigned char* __restrict__ img16, int KC)
 {
     __shared__ MidScratch ms[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void hm_merge_rows_kernel(float* __restrict__ 
     if (t >= count) return;
     hm_wave_stage_rows(img, RS, d, I[t], J[t], ms[wv], lane);
     const float r2 = hm_wave_midpoint(d, W[t], c, sign_mode, ms[wv], true, lane);
-    hm_wave_store_row(ms[wv], r2, d, RS, KS, X, ld, img, img16, first_row + t, rmax2_bits, lane);
+    hm_wave_store_row(ms[wv], r2, d, RS, KC, X, ld, img, img16, first_row + t, rmax2_bits, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void hm_coherence_kernel(const float* __restri
 // 64 rows per block are staged through LDS with coalesced loads; a thread then runs its row's fmaf chain
 // (the canonical order of project is sequential) on LDS operands.
 __global__ __launch_bounds__(64) void hm_project_table_kernel(float* __restrict__ X, int64_t ld, int d, int64_t n_rows, float c,
-                                                              float* __restrict__ img, int RS, unsigned char* __restrict__ img16, int KS,
+                                                              float* __restrict__ img, int RS, unsigned char* __restrict__ img16, int KC,
                                                               int64_t n_live, uint32_t* __restrict__ rmax2_bits)
 {
     extern __shared__ float tile[];                           // 64 x stride
@@ -281,13 +281,13 @@ __global__ __launch_bounds__(64) void hm_project_table_kernel(float* __restrict_
         X[row * ld] = x0;
         if (row < n_live) {
             img[row * RS + RS - 4] = x0;
-            const int CH = 2 * KS + 1;
+            const int CH = hm_row16_chunks(KC);
             unsigned char* r16 = img16 + row * CH * 16;
-            *reinterpret_cast<uint32_t*>(r16 + (CH - 1) * 16) = hm::fbits(x0);
-            if (KS > 0) {
+            if (CH > KC) *reinterpret_cast<uint32_t*>(r16 + KC * 16) = hm::fbits(x0);
+            if (KC > 0) {
                 const __bf16 hb = (__bf16)x0;
                 const float hi = (float)hb, lo = x0 - hi;
-                uint32_t* slots = reinterpret_cast<uint32_t*>(r16 + (2 * KS - 1) * 16 + 8);   // K-slots 8c+4 .. 8c+7 of the last chunk
+                uint32_t* slots = reinterpret_cast<uint32_t*>(r16 + (KC - 1) * 16 + 8);       // K-slots 8c+4 .. 8c+7 of the last chunk
                 slots[0] = hm_pack_bf16(hi, lo);
                 slots[1] = hm_pack_bf16(hi, 0.0f);
             }
@@ -485,7 +485,7 @@ extern "C" int hm_merge_append(hm_engine* e, int32_t i, int32_t j, float w, floa
         return hm_fail(e, HM_E_ARG, "hm_merge_append: bad arguments");
     HM_HIP(hipSetDevice(e->device));
     hipLaunchKernelGGL(hm_merge_append_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d, i, j, w, c,
-                       e->sign_mode, X_dev, ld, new_row, e->d_rmax2, e->img16, e->KS);
+                       e->sign_mode, X_dev, ld, new_row, e->d_rmax2, e->img16, e->KC);
     HM_HIP(hipGetLastError());
     hm_rows_changed(e, new_row, (hipStream_t)stream);
     if (new_row + 1 > e->n) e->n = new_row + 1;
@@ -503,10 +503,10 @@ extern "C" int hm_merge_append_batch(hm_engine* e, const int32_t* I_dev, const i
     if (count == 0) return HM_OK;
     if (independent)
         hipLaunchKernelGGL(hm_merge_rows_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, (hipStream_t)stream, e->img, e->RS, e->d,
-                           I_dev, J_dev, W_dev, (int)count, c, e->sign_mode, X_dev, ld, first_row, e->d_rmax2, e->img16, e->KS);
+                           I_dev, J_dev, W_dev, (int)count, c, e->sign_mode, X_dev, ld, first_row, e->d_rmax2, e->img16, e->KC);
     else
         hipLaunchKernelGGL(hm_merge_batch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e->img, e->RS, e->d, I_dev, J_dev, W_dev,
-                           (int)count, c, e->sign_mode, X_dev, ld, first_row, e->d_rmax2, e->img16, e->KS);
+                           (int)count, c, e->sign_mode, X_dev, ld, first_row, e->d_rmax2, e->img16, e->KC);
     HM_HIP(hipGetLastError());
     hm_rows_changed(e, first_row, (hipStream_t)stream);
     if (first_row + count > e->n) e->n = first_row + count;
@@ -568,7 +568,7 @@ extern "C" int hm_project_table(hm_engine* e, float* X_dev, int64_t ld, int64_t 
     HM_HIP(hipMemsetAsync(e->d_rmax2, 0, sizeof(uint32_t) * 2, s));
     const size_t lds = sizeof(float) * 64 * (size_t)(e->d + 2);
     hipLaunchKernelGGL(hm_project_table_kernel, dim3((unsigned)((n_rows + 63) / 64)), dim3(64), lds, s, X_dev, ld, e->d, n_rows, c,
-                       e->img, e->RS, e->img16, e->KS, e->n, e->d_rmax2);
+                       e->img, e->RS, e->img16, e->KC, e->n, e->d_rmax2);
     HM_HIP(hipGetLastError());
     // every live row changed
     e->armed = false;

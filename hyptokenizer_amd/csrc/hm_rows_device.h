@@ -75,7 +75,7 @@ __device__ __forceinline__ float hm_wave_midpoint(int d, float w, float c, int s
 
 // write ms.so as row `row` of the caller's table (may be nullptr), of the fp32 image and of the bf16 image, and
 // fold its norms into the bounds the pair scan's error margin uses
-__device__ __forceinline__ void hm_wave_store_row(MidScratch& ms, float r2, int d, int RS, int KS, float* __restrict__ X, int64_t ld,
+__device__ __forceinline__ void hm_wave_store_row(MidScratch& ms, float r2, int d, int RS, int KC, float* __restrict__ X, int64_t ld,
                                                   float* __restrict__ img, unsigned char* __restrict__ img16, int64_t row,
                                                   uint32_t* __restrict__ rmax2_bits, int lane)
 {
@@ -94,11 +94,11 @@ __device__ __forceinline__ void hm_wave_store_row(MidScratch& ms, float r2, int 
         if (k == 0) ir[RS - 4] = v;
         else ir[hm_img_off(k - 1)] = v;
     }
-    const int CH = 2 * KS + 1;
+    const int CH = hm_row16_chunks(KC);
     for (int cidx = lane; cidx < CH; cidx += 64) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (cidx == CH - 1) v.x = hm::fbits(ms.so[0]);
-        else v = hm_bf16_chunk(ms.so + 1, ms.so[0], d, KS, cidx);
+        if (cidx >= KC) v.x = hm::fbits(ms.so[0]);
+        else v = hm_bf16_chunk(ms.so + 1, ms.so[0], d, KC, cidx);
         *reinterpret_cast<uint4*>(img16 + ((int64_t)row * CH + cidx) * 16) = v;
     }
 }

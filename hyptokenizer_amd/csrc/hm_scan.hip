@@ -14,7 +14,8 @@
 //
 // Two prefilter forms, one result (every reported distance is re-evaluated canonically, hm_search.hip):
 //   BF = 0  v_mfma_f32_32x32x2_f32 on the fp32 image (exact fmaf chain; NG = groups of 4 spatial coordinates)
-//   BF = 1  v_mfma_f32_32x32x16_bf16 on the bf16 image (NG = k-steps of 16; time coordinate in split slots)
+//   BF = 1  v_mfma_f32_32x32x16_bf16 on the bf16 image (NG = chunks of 8 K-slots, two per k-step; an odd count ends on
+//           one v_mfma_f32_32x32x8_bf16_1k half step; time coordinate in split slots)
 // A bound delta >= |u_f - u_c| (hm_scan_delta) widens every comparison.
 #include <type_traits>
 
@@ -35,7 +36,7 @@
 #define HM_WPB_BIG 8               // bf16 form, large launches: 8 waves x 64 rows = 512-row blocks (half the L2 -> LDS fill traffic)
 #endif
 #ifndef HM_SCAN_INSTANTIATE_ALL
-#define HM_SCAN_INSTANTIATE_ALL 1  // 0: only d = 100 (KS = 7 / NG = 25) -- quick builds for tuning runs
+#define HM_SCAN_INSTANTIATE_ALL 1  // 0: only d = 100 (13 chunks / NG = 25) -- quick builds for tuning runs
 #endif
 
 // CNT (1..4) consecutive 1 KiB LDS-DMA pieces in one statement: one M0 write; the immediate offset of
@@ -79,17 +80,26 @@ __device__ __forceinline__ void hm_dma_run(const char* src, uint32_t dst)
 #ifndef HM_SCAN_DEEP_PREFETCH
 #define HM_SCAN_DEEP_PREFETCH 1
 #endif
+#ifndef HM_SCAN_HALVES
+#define HM_SCAN_HALVES 0           // bf16 form, 128-row waves: the wave's rows as two 64-row halves with alternating accumulator sets
+#endif
 template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int SUB>
 __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
 {
     static_assert(SUB % 2 == 0, "the two accumulator sets alternate between column groups: an even number per tile");
-    constexpr bool PIPE = (TM <= HM_SCAN_PIPE_MAX_TM);   // two accumulator sets fit the registers (128 stationary rows per wave: one set)
+    // 128-row waves (TM = 4), bf16 form: the wave's rows are worked as two 64-row HALVES per column group; the two
+    // accumulator sets belong to the halves, so the bound test of one half rides in the other half's MFMAs exactly as the
+    // 64-row waves' column groups do -- with half the streamed bytes, LDS-DMA instructions and fragment reads per flop
+    constexpr bool HALVES = (BF != 0) && (TM == 4) && HM_SCAN_HALVES;
+    constexpr int TMI = HALVES ? 2 : TM;                 // 32-row MFMA tiles per accumulator set
+    constexpr bool PIPE = !HALVES && (TM <= HM_SCAN_PIPE_MAX_TM);   // two accumulator sets alternating between column groups
     constexpr int COLS = 32 * SUB;                 // partner rows per streamed tile
     constexpr int RS = hm_row_floats(NG);          // fp32 image: floats per row
-    constexpr int RB16 = 32 * NG + 16;             // bf16 image: bytes per row (NG x 16 bf16 + [x0 fp32, pad])
+    constexpr int RB16 = 16 * hm_row16_chunks(NG); // bf16 image: bytes per row (NG chunks of 8 bf16 [+ the [x0 fp32] chunk])
+    constexpr bool HALF_LAST = (BF != 0) && (NG & 1);   // the last k-step covers one chunk only (8 K-slots)
     constexpr int ROW_BYTES = BF ? RB16 : RS * 4;
     constexpr int TILE_BYTES = COLS * ROW_BYTES;
-    constexpr int NP = BF ? NG : NG + 1;           // k-steps: fp32: NG spatial groups + time; bf16: NG steps of 16
+    constexpr int NP = BF ? (NG + 1) / 2 : NG + 1; // k-steps: fp32: NG spatial groups + time; bf16: two chunks per step
     constexpr int NPIECE = TILE_BYTES / 1024;      // 1 KiB pieces per tile
     constexpr int TCH = RS / 4 - 1;                // fp32 image: chunk index of the time group
     constexpr int PPW = (NPIECE + WPB - 1) / WPB;  // LDS-DMA pieces per wave and tile (slot padded to PPW * WPB KiB)
@@ -104,6 +114,25 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF * TILE_LDS (+ hist)
 
     if (p.stop != nullptr && *p.stop != 0u) return;     // a device-resident loop has ended
+#if defined(HM_DIAG_STAMPS)
+    // diagnostic build only (tools/scan_stamps.py): shader cycles of one wave spent per phase, summed over the waves into
+    // p.diag: [0] whole kernel [1] unit dequeue [2] stationary rows + ring prologue [3] tile loops [4] counted DMA wait
+    // [5] per-tile barrier [6] slow path [7] waves [8] units
+    unsigned long long dg[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dg_units = 0;
+    const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long dg_r0 = __builtin_amdgcn_s_memrealtime();
+#if HM_DIAG_STAMPS >= 2        // light form: per-block and per-unit stamps only, nothing inside the tile loop
+#define HM_STAMP(var) const unsigned long long var = 0
+#define HM_ACC(idx, a, b)
+#else
+#define HM_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define HM_ACC(idx, a, b) dg[idx] += (b) - (a)
+#endif
+#else
+#define HM_STAMP(var)
+#define HM_ACC(idx, a, b)
+#endif
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -128,7 +157,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
 
     // The MFMA result u_f (plain fmaf chain) and the canonical u_c (torch reduction order) are two
     // roundings of the same exact form; |u_f - u_c| <= delta (gamma_n bound on both, |terms| <= rmax2).
-    const float delta = hm_scan_delta(BF != 0, BF ? 16 * NG : RS, p.rmax2_bits);
+    const float delta = hm_scan_delta(BF != 0, BF ? 8 * NG : RS, p.rmax2_bits);
     const float pre_f = p.u_hi + delta;              // candidate prefilter on u_f
     const float lo_f = p.u_lo - delta;               // u_f below this: canonical d < thr for sure
     const float zmax_f = 1.0f - delta;               // u_f at or below this: canonical u <= 1, d == 0
@@ -144,20 +173,39 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     // ---- stationary A fragments: lane (r, h) keeps its operands of every k-step in registers ----
     float2 a[BF ? 1 : TM][BF ? 1 : NP];            // fp32 form: 2 operands (two k-steps) per group
     uint4 a16[BF ? TM : 1][BF ? NP : 1];           // bf16 form: 8 bf16 per 16-wide k-step
+    // bf16 form: the k-step g operand of a lane from its row pointer (row start + 16 * h): 8 K-slots = one 16-byte chunk;
+    // the half step of an odd chunk count holds 4 slots per lane (8 bytes at chunk start + 8 * h)
+    auto frag_at = [&](const auto* base, int g) -> uint4 {
+        const char* q = reinterpret_cast<const char*>(base);
+        if (HALF_LAST && g == NP - 1) {
+            const uint2 v = *reinterpret_cast<const uint2*>(q + 32 * g - 8 * h);
+            return make_uint4(v.x, v.y, 0u, 0u);
+        }
+        return *reinterpret_cast<const uint4*>(q + 32 * g);
+    };
+    auto mfma16 = [&](const uint4& av, const uint4& bv, const f32x16& cv, int g) -> f32x16 {
+        if (HALF_LAST && g == NP - 1) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            const uint2 a2 = make_uint2(av.x, av.y), b2 = make_uint2(bv.x, bv.y);
+            return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, a2), __builtin_bit_cast(s16x4, b2), cv, 0, 0, 0);
+        }
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), cv, 0, 0, 0);
+    };
     auto load_a = [&]() {
     if constexpr (BF) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const unsigned char* src = p.img16 + (int64_t)(i0w + 32 * tm + r) * RB16 + 16 * h;
 #pragma unroll
-            for (int g = 0; g < NP; ++g) a16[tm][g] = *reinterpret_cast<const uint4*>(src + 32 * g);
+            for (int g = 0; g < NP; ++g) a16[tm][g] = frag_at(src, g);
             // stationary side of the time product: [hi, lo, hi, 0] -> [-hi, -hi, -lo, 0] (last 4 slots,
             // held by the h = 1 half of the last k-step)
             if (h == 1) {
-                const uint32_t z = a16[tm][NP - 1].z;
+                const uint32_t z = HALF_LAST ? a16[tm][NP - 1].x : a16[tm][NP - 1].z;
                 const uint32_t hi16 = z & 0xffffu, lo16 = z >> 16;
-                a16[tm][NP - 1].z = (hi16 | (hi16 << 16)) ^ 0x80008000u;
-                a16[tm][NP - 1].w = lo16 ^ 0x8000u;
+                const uint32_t t0 = (hi16 | (hi16 << 16)) ^ 0x80008000u, t1 = lo16 ^ 0x8000u;
+                if (HALF_LAST) { a16[tm][NP - 1].x = t0; a16[tm][NP - 1].y = t1; }
+                else { a16[tm][NP - 1].z = t0; a16[tm][NP - 1].w = t1; }
             }
         }
     } else {
@@ -182,7 +230,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     };
 
     // ---- per-group pieces ----
-    f32x16 acc[PIPE ? 2 : 1][TM];                   // two accumulator sets (see the header) where they fit
+    f32x16 acc[(PIPE || HALVES) ? 2 : 1][TMI];      // two accumulator sets (see the header) where they fit
+    uint4 bh[HALVES ? NP : 1];                      // HALVES: the k-step fragments of the column group at hand (both halves use them)
     uint4 bpre16 = make_uint4(0, 0, 0, 0);          // first B fragment of the NEXT group, requested by the previous one
     // bf16 form with two accumulator sets: ALL k-step fragments of a column group are in registers before its MFMAs
     // start -- requested while the previous group of the tile computes (two register sets, alternating like the
@@ -218,22 +267,20 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         };
         if constexpr (BF) {
             const char* bt = smem + buf * TILE_LDS + (sub * 32 + r) * RB16 + 16 * h;
-            if (fresh) bpre16 = *reinterpret_cast<const uint4*>(bt);
+            if (fresh) bpre16 = frag_at(bt, 0);
             uint4 bc = bpre16, bn = bc;
 #pragma unroll
             for (int g = 0; g < NP; ++g) {
-                bn = *reinterpret_cast<const uint4*>(bt + (g + 1 < NP ? 32 * (g + 1) : 32 * RB16));
+                bn = g + 1 < NP ? frag_at(bt, g + 1) : frag_at(bt + 32 * RB16, 0);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
                     if (g == 0) {
                         f32x16 z;
 #pragma unroll
                         for (int e = 0; e < 16; ++e) z[e] = 0.0f;
-                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
-                                                                              __builtin_bit_cast(bf16x8, bc), z, 0, 0, 0);
+                        acc[set][tm] = mfma16(a16[tm][g], bc, z, g);
                     } else {
-                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
-                                                                              __builtin_bit_cast(bf16x8, bc), acc[set][tm], 0, 0, 0);
+                        acc[set][tm] = mfma16(a16[tm][g], bc, acc[set][tm], g);
                     }
                 }
                 fold(g);
@@ -283,7 +330,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             const char* bt = smem + buf * TILE_LDS + (sub * 32 + r) * RB16 + 16 * h;
             if (fresh) {
 #pragma unroll
-                for (int g = 0; g < NP; ++g) bfr[set][g] = *reinterpret_cast<const uint4*>(bt + 32 * g);
+                for (int g = 0; g < NP; ++g) bfr[set][g] = frag_at(bt, g);
             }
             ext = acc[set ^ 1][0][0];
             auto kstep = [&](int g) {
@@ -293,11 +340,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
                         f32x16 z;
 #pragma unroll
                         for (int e = 0; e < 16; ++e) z[e] = 0.0f;
-                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
-                                                                              __builtin_bit_cast(bf16x8, bfr[set][g]), z, 0, 0, 0);
+                        acc[set][tm] = mfma16(a16[tm][g], bfr[set][g], z, g);
                     } else {
-                        acc[set][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16[tm][g]),
-                                                                              __builtin_bit_cast(bf16x8, bfr[set][g]), acc[set][tm], 0, 0, 0);
+                        acc[set][tm] = mfma16(a16[tm][g], bfr[set][g], acc[set][tm], g);
                     }
                 }
 #pragma unroll
@@ -315,11 +360,58 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             // the path WITHOUT the requests, which in the path with them means waiting for the requests themselves
             (void)prefetch;
 #pragma unroll
-            for (int g = 0; g < NP; ++g) bfr[set ^ 1][g] = *reinterpret_cast<const uint4*>(bt + 32 * RB16 + 32 * g);
+            for (int g = 0; g < NP; ++g) bfr[set ^ 1][g] = frag_at(bt + 32 * RB16, g);
             __builtin_amdgcn_sched_barrier(0);      // the requests stay in front of the remaining MFMAs
 #pragma unroll
             for (int g = 1; g < NP; ++g) kstep(g);
             ext = SIGN ? -ext : ext;
+        }
+    };
+
+    // HALVES: the k-steps of column group `sub` for the wave's row half H into acc[H], with the group's fragments in bh[]
+    // (`fresh`: they are loaded here first; else the previous group's second half has requested them).  FOLD: the bound test's
+    // reduction over the OTHER half's finished accumulators rides in the MFMAs' issue shadow, as in mma_group.  REFILL (second
+    // half of a group): once k-step g's MFMAs are out, bh[g] is requested anew from the NEXT column group -- unconditionally
+    // (behind a tile's last group the addresses fall into the next slot or the slack behind the ring, never used) -- so every
+    // fragment of the next group has at least six k-steps of MFMAs to arrive behind.
+    auto mma_half = [&](auto half_c, auto fold_c, auto refill_c, int buf, int sub, bool fresh, float& ext) {
+        constexpr int H = decltype(half_c)::value;
+        constexpr bool FOLD = decltype(fold_c)::value, REFILL = decltype(refill_c)::value;
+        constexpr int QN = 16 * TMI;
+        if constexpr (HALVES) {
+            const char* bt = smem + buf * TILE_LDS + (sub * 32 + r) * RB16 + 16 * h;
+            if (fresh) {
+#pragma unroll
+                for (int g = 0; g < NP; ++g) bh[g] = frag_at(bt, g);
+            }
+            if constexpr (FOLD) ext = acc[H ^ 1][0][0];
+#pragma unroll
+            for (int g = 0; g < NP; ++g) {
+#pragma unroll
+                for (int tm = 0; tm < TMI; ++tm) {
+                    if (g == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) z[e] = 0.0f;
+                        acc[H][tm] = mfma16(a16[2 * H + tm][g], bh[g], z, g);
+                    } else {
+                        acc[H][tm] = mfma16(a16[2 * H + tm][g], bh[g], acc[H][tm], g);
+                    }
+                }
+                if constexpr (FOLD) {
+#pragma unroll
+                    for (int q = (g * QN) / NP; q < ((g + 1) * QN) / NP; ++q) {
+                        const float v = acc[H ^ 1][q / 16][q % 16];
+                        ext = SIGN ? __builtin_fmaxf(ext, v) : __builtin_fminf(ext, v);
+                    }
+                }
+                if constexpr (REFILL) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    bh[g] = frag_at(bt + 32 * RB16, g);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if constexpr (FOLD) ext = SIGN ? -ext : ext;
         }
     };
 
@@ -328,7 +420,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         constexpr int set = decltype(set_c)::value;
         float ext = acc[set][0][0];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TMI; ++tm)
 #pragma unroll
             for (int e = 0; e < 16; ++e) ext = SIGN ? __builtin_fmaxf(ext, acc[set][tm][e]) : __builtin_fminf(ext, acc[set][tm][e]);
         return SIGN ? -ext : ext;
@@ -338,8 +430,10 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     // a time (a rolled loop: the hot loop must not inherit its register pressure).  Per-element predicates are
     // evaluated twice (count, then write); the second evaluation runs on laundered copies of the bounds so that the
     // compiler does not keep the predicates alive across the wave scan.
-    auto finish_group = [&](auto set_c, float ext_u, int j0s) {
+    auto finish_group = [&](auto set_c, float ext_u, int j0s, int row_off = 0) -> bool {
         constexpr int set = decltype(set_c)::value;
+        const int i0h = i0w + row_off;               // first row of the accumulator set's rows (HALVES: the wave's second half starts 64 rows down)
+        constexpr int SET_ROWS = 32 * TMI;
         float bound_f = pre_f;
         uint32_t best_bits = 0xffffffffu, best_low = 0xffffffffu;
         if (MODE == HM_MODE_TOPK && !p.count_sure && !cut_all && cut_f < bound_f) bound_f = cut_f;   // nothing above the cut is visited
@@ -353,30 +447,31 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
                 if (bb < bound_f) bound_f = bb;
             }
         }
-        if (__ballot(ext_u < bound_f) == 0ull) return;
+        if (__ballot(ext_u < bound_f) == 0ull) return false;
         if (MODE == HM_MODE_ARGMIN && best_bits == 0x3f7fffffu && p.thr_pos != 0) {
             // The running best is a pair at distance exactly 0 (the literal sign mode: EVERY pair is one).  A pair that is
             // certainly at distance 0 too is only emitted when its (i, j) orders before the best's (`low <= best_low`
             // below); every pair of this group has low >= lowmin.  So when the whole group is certainly-zero and starts
             // behind the best pair, the slow path would emit nothing: skip it (1.6 ms -> 0.3 ms per tie-flood scan).
-            const uint32_t lowmin = ((uint32_t)i0w << 15) | ((uint32_t)j0s >> 2);
+            const uint32_t lowmin = ((uint32_t)i0h << 15) | ((uint32_t)j0s >> 2);
             if (lowmin > best_low) {
                 float worst = SIGN ? -acc[set][0][0] : acc[set][0][0];          // the LARGEST u of the lane's elements
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+                for (int tm = 0; tm < TMI; ++tm)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const float u = SIGN ? -acc[set][tm][e] : acc[set][tm][e];
                         worst = __builtin_fmaxf(worst, u);
                     }
-                if (__ballot(!(worst <= zmax_f)) == 0ull) return;                // (NaN counts as not certainly zero)
+                if (__ballot(!(worst <= zmax_f)) == 0ull) return false;          // (NaN counts as not certainly zero)
             }
         }
-        const bool full = rows_full && (j0s > i0w + WAVE_ROWS - 1) && (j0s + 31 < p.n) && (j0s >= p.col_begin);
+        HM_STAMP(sp0);
+        const bool full = rows_full && (j0s > i0h + SET_ROWS - 1) && (j0s + 31 < p.n) && (j0s >= p.col_begin);
         unsigned long long wkey = ~0ull;
         bool wrote = false;
 #pragma unroll 1
-        for (int st = 0; st < TM; ++st) {
+        for (int st = 0; st < TMI; ++st) {
             // element-wise select chain: a whole-vector `if (st == q) w = acc[q]` makes hipcc keep the accumulators
             // in scratch memory in some instantiations (3x slower hot loop)
             f32x16 w;
@@ -384,10 +479,10 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             for (int e = 0; e < 16; ++e) {
                 float v = acc[set][0][e];
 #pragma unroll
-                for (int q = 1; q < TM; ++q) v = (st == q) ? acc[set][q][e] : v;
+                for (int q = 1; q < TMI; ++q) v = (st == q) ? acc[set][q][e] : v;
                 w[e] = v;
             }
-            if (TM > 1) {
+            if (TMI > 1) {
                 float e1 = w[0];
 #pragma unroll
                 for (int e = 1; e < 16; ++e) e1 = SIGN ? __builtin_fmaxf(e1, w[e]) : __builtin_fminf(e1, w[e]);
@@ -397,7 +492,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             float bnd = bound_f;
             float cutv = cut_f;
             unsigned long long slot = 0;
-            const int ib = i0w + 32 * st + 4 * h;
+            const int ib = i0h + 32 * st + 4 * h;
             const int j = j0s + r;
             auto visit = [&](const float wv, const int e, const bool write) {
                 const float u = SIGN ? -wv : wv;
@@ -461,37 +556,81 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             gk = __hip_atomic_load(&p.ctr64[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (wk < gk) gk = wk;
         }
+        HM_STAMP(sp1);
+        HM_ACC(6, sp0, sp1);
+        return true;
     };
 
     // ---- work distribution ----
-    // HIST launches (sampled estimate passes): static, block b owns item b of the host's list.
-    // TOPK / ARGMIN launches (p.persist): the tiles right of the diagonal of the launch's row blocks, in row-major order,
-    // form ONE sequence of p.p_total tiles; the grid is exactly the blocks that are resident at once, and block b walks
-    // the share [b, b + 1) * p_total / gridDim.x of it -- equal work per block, no launch tail, one block start per
-    // slot -- reloading its stationary rows when the share crosses into the next row block (once or twice per block).
-    constexpr int TPR = BLOCK_ROWS / COLS;                     // diagonal advance per row block, in tiles
-    static_assert(BLOCK_ROWS % COLS == 0, "row blocks start on a tile boundary");
-    // tiles of the sequence in front of relative row block q
-    auto seq_before = [&](long long q) { return q * p.nct - (long long)TPR * ((long long)p.rb_first * q + q * (q - 1) / 2); };
-    long long pos = 0, pos_end = 0;
-    if (p.persist) {
-        pos = p.p_total * (long long)blockIdx.x / (long long)gridDim.x;
-        pos_end = p.p_total * ((long long)blockIdx.x + 1) / (long long)gridDim.x;
+    // HIST launches (sampled estimate passes) and small launches: static, block b owns item b of the host's list.
+    // Large TOPK / ARGMIN launches (p.xq): XCD-sliced unit queues.  The column tiles are dealt to the eight XCDs by
+    // tile index modulo 8, so the partner rows one XCD ever streams are a fixed eighth of the image (1.5 MB of the
+    // 12 MB bf16 image at 50 k rows): after the first touch they are served by that XCD's own 4 MiB L2, whatever the
+    // blocks' relative timing.  A unit = (row block, slice): the tiles of that slice right of the row block's diagonal,
+    // walked with stride 8.  Each slice has a queue of its units in order of decreasing size (row blocks top down)
+    // and a head counter in HBM; the grid is the resident blocks, a block pulls units from the queue of the XCD it
+    // runs on (HW_REG_XCC_ID) and, once that queue is empty, from the nearest non-empty one -- longest units first,
+    // the tail made of the shortest.  Placement is a speed matter only: every unit is pulled exactly once whichever
+    // XCD a block runs on, a block never waits for another one, and the block that leaves last re-zeroes the heads.
+    constexpr int XQ_SLICES = 8;
+    __shared__ int s_unit[2];
+    int xq_q = 0;                        // queue the next unit is asked from: the own XCD's, later the one stolen from
+    uint32_t xq_next = 0xffffffffu;      // wave 0: unit index the previous unit's look-ahead add returned (all ones: none asked)
+    if (p.xq) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xq_q = (int)(xcc & 7u);
     }
+    int ct_step = 1;
     for (;;) {
-    if (p.persist) {
-        if (pos >= pos_end) break;
-        int lo = 0, hi = p.n_rb - 1;                           // largest q with seq_before(q) <= pos
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (seq_before(mid) <= pos) lo = mid; else hi = mid - 1;
+    if (p.xq) {
+        HM_STAMP(dq0);
+        if (wave == 0) {
+            int q = -1;
+            uint32_t u = 0;
+            // the look-ahead add was issued when the previous unit started; its value is in by now (the tile loop ends on
+            // s_waitcnt vmcnt(0)) -- one more wait, visible to the register allocator, settles it
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xq_next) : : "memory");
+            uint32_t got = __builtin_amdgcn_readfirstlane(xq_next);
+            int qq = xq_q;
+            for (;;) {                                            // (heads only grow: at most 8 * n_rb + 8 rounds)
+                if (got == 0xffffffffu) {                         // nothing asked yet (first unit, or after a miss)
+                    uint32_t g2 = 0;
+                    if (lane == 0) g2 = __hip_atomic_fetch_add(&p.xq_heads[32 * qq], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    got = __builtin_amdgcn_readfirstlane(g2);
+                }
+                if (got < (uint32_t)p.n_rb) { q = qq; u = got; break; }
+                // that queue is empty: the nearest one that still has units (cyclic from the own XCD's)
+                uint32_t hv = 0xffffffffu;
+                if (lane < XQ_SLICES) hv = __hip_atomic_load(&p.xq_heads[32 * ((xq_q + lane) & 7)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long open = __ballot(lane < XQ_SLICES && hv < (uint32_t)p.n_rb);
+                if (open == 0ull) break;
+                qq = (xq_q + (int)__builtin_ctzll(open)) & 7;
+                got = 0xffffffffu;
+            }
+            if (lane == 0) { s_unit[0] = q; s_unit[1] = (int)u; }
         }
-        const long long q0 = seq_before(lo), q1 = seq_before(lo + 1);
-        const long long run_end = pos_end < q1 ? pos_end : q1;
-        rb = p.rb_first + lo;
-        ct0 = rb * TPR + (int)(pos - q0);
-        ct1 = ct0 + (int)(run_end - pos);
-        pos = run_end;
+        __syncthreads();
+        const int q = s_unit[0], u = s_unit[1];
+        __syncthreads();
+        HM_STAMP(dq1);
+        HM_ACC(1, dq0, dq1);
+        if (q < 0) break;
+        xq_q = q;
+        xq_next = 0xffffffffu;
+        if (wave == 0) {
+            // look-ahead: ask for this block's NEXT unit now (a load the compiler does not see: it would wait for it inside the
+            // tile loop); units asked for beyond a queue's end only push its head past n_rb
+            const uint32_t one = 1u;
+            const uint32_t* hp = &p.xq_heads[32 * q];
+            if (lane == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(xq_next) : "v"(hp), "v"(one) : "memory");
+        }
+        rb = p.rb_first + u;
+        int c_lo = (rb * BLOCK_ROWS) / COLS;
+        if (c_lo < p.col_begin / COLS) c_lo = p.col_begin / COLS;
+        ct0 = c_lo + ((q - c_lo) & (XQ_SLICES - 1));          // first tile of slice q at or right of c_lo
+        ct1 = p.nct;
+        ct_step = XQ_SLICES;
     } else if ((int)blockIdx.x < p.n_items_a) {
         rb = p.rb_first + (int)blockIdx.x / p.chunks_a;
         ct0 = p.ctmin_a + ((int)blockIdx.x % p.chunks_a) * p.ch_a;
@@ -505,8 +644,13 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     if (ct0 < (rb * BLOCK_ROWS) / COLS) ct0 = (rb * BLOCK_ROWS) / COLS;   // left of the diagonal: no i < j
     if (ct0 < p.col_begin / COLS) ct0 = p.col_begin / COLS;               // partner rows in front of col_begin are not asked for
     if (ct1 > p.nct) ct1 = p.nct;
-    if (ct0 >= ct1) { if (p.persist) continue; else break; }
+    if (ct0 >= ct1) { if (p.xq) continue; else break; }
 
+    HM_STAMP(pr0);
+#if defined(HM_DIAG_STAMPS)
+    dg_units += 1;
+    const unsigned long long dg_ur0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (rb != rb_cur) {
         rb_cur = rb;
         i0w = rb * BLOCK_ROWS + wave * WAVE_ROWS;
@@ -516,7 +660,6 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     }
 
     // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
-    int ct_step = 1;
     if (MODE == HM_MODE_HIST) {
         ct_step = p.sample_stride;
         ct0 += (ct_step - (ct0 + rb * 7) % ct_step) % ct_step;
@@ -535,6 +678,8 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     // A wait it can see, here, settles them before the loop is entered.
     if (DIST == 1) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
     __syncthreads();
+    HM_STAMP(pr1);
+    HM_ACC(2, pr0, pr1);
 
     bool pend = false;               // a finished group waits in the other accumulator set for its bound test
     bool deep_valid = false;         // bfr[0] holds the fragments of the group about to run (requested by its predecessor)
@@ -557,7 +702,36 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         }
         dma_tile(ct_next, buf_next);
 
-        if constexpr (!PIPE) {
+        if constexpr (HALVES) {
+            // 128-row waves as two halves: per column group, half 0's MFMAs carry the test of the pending half 1 (of the group
+            // before), half 1's MFMAs carry half 0's test and request the next group's fragments.  One code site per half:
+            // a group whose second half lies left of the diagonal computes it all the same (its pairs have i >= j: masked)
+#pragma unroll 1
+            for (int sub = 0; sub < SUB; ++sub) {
+                const int j0s = j0 + sub * 32;
+                const bool act0 = wave_active && (j0s + 31 > i0w);
+                const bool act1 = wave_active && (j0s + 31 > i0w + 64);            // (act1 implies act0)
+                if (!act0) {
+                    if (pend) {
+                        const float ext_u = reduce_group(std::integral_constant<int, 1>{});
+                        finish_group(std::integral_constant<int, 1>{}, ext_u, pend_j0s, 64);
+                        pend = false;
+                    }
+                    deep_valid = false;
+                    continue;
+                }
+                float ea = 0.0f, eb = 0.0f;
+                mma_half(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{}, buf, sub, !deep_valid, ea);
+                // (the fragments do not live across a slow path: they are read again behind it)
+                bool slow_a = false;
+                if (pend) slow_a = finish_group(std::integral_constant<int, 1>{}, ea, pend_j0s, 64);
+                mma_half(std::integral_constant<int, 1>{}, std::true_type{}, std::true_type{}, buf, sub, slow_a, eb);
+                const bool slow_b = finish_group(std::integral_constant<int, 0>{}, eb, j0s, 0);
+                pend = act1;
+                pend_j0s = j0s;
+                deep_valid = !slow_b && (sub + 1 < SUB);                            // bh[] holds the fragments of the tile's next group
+            }
+        } else if constexpr (!PIPE) {
             // one accumulator set: MFMAs, then the bound test of the same group (the other resident block of the CU
             // fills the matrix pipe meanwhile); the first fragment of the next group is still requested early
             bool prev = false;
@@ -626,25 +800,71 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         }
 
         // tile t+1 has landed (this wave's pieces) -- and so has the key load, if one was issued
+        HM_STAMP(tw0);
         if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gk_raw) : : "memory");
         else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gk_raw) : "n"((DIST - 1) * PPW) : "memory");
         if (MODE == HM_MODE_ARGMIN && gk_pending) {
             if (gk_raw < gk) gk = gk_raw;                   // the key only ever decreases
             gk_pending = false;
         }
+        HM_STAMP(tw1);
         __syncthreads();                                     // ... and every wave's; all reads of slot `buf` done
+        HM_STAMP(tw2);
+        HM_ACC(4, tw0, tw1);
+        HM_ACC(5, tw1, tw2);
         if (++buf == NBUF) buf = 0;
     }
-    if constexpr (PIPE) {
-        if (pend) {                                          // the last group of the run (set (SUB - 1) % 2 = 1)
+    if constexpr (PIPE || HALVES) {
+        if (pend) {                                          // the last group of the run (set (SUB - 1) % 2 = 1; HALVES: its second half)
             const float ext_u = reduce_group(std::integral_constant<int, 1>{});
-            finish_group(std::integral_constant<int, 1>{}, ext_u, pend_j0s);
+            finish_group(std::integral_constant<int, 1>{}, ext_u, pend_j0s, HALVES ? 64 : 0);
         }
     }
 
     if (DIST > 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // nothing of this run may land later
-    if (!p.persist) break;
+    HM_STAMP(tl1);
+    HM_ACC(3, pr1, tl1);
+#if defined(HM_DIAG_STAMPS)
+    if (p.diag != nullptr && threadIdx.x == 0) {
+        const unsigned long long slot = atomicAdd(&p.diag[9], 1ull);
+        if (slot < 4096) {
+            unsigned long long* u = p.diag + 16 + 4 * 8192 + 8 * slot;
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            u[0] = blockIdx.x; u[1] = xcc & 7u; u[2] = (unsigned long long)rb; u[3] = (unsigned long long)ct0; u[4] = (unsigned long long)ntile;
+            u[5] = dg_ur0; u[6] = __builtin_amdgcn_s_memrealtime(); u[7] = pr1 - pr0;
+        }
+    }
+#endif
+    if (!p.xq) break;
     }   // work loop
+
+#if defined(HM_DIAG_STAMPS)
+    if (p.diag != nullptr && lane == 0) {
+        dg[0] = __builtin_amdgcn_s_memtime() - dg_t0;
+        for (int q = 0; q < 7; ++q) atomicAdd(&p.diag[q], dg[q]);
+        atomicAdd(&p.diag[7], 1ull);
+        if (wave == 0) {
+            atomicAdd(&p.diag[8], dg_units);
+            if (blockIdx.x < 8192) {          // per-block lifetime on the 100 MHz clock, XCD, units
+                p.diag[16 + 4 * blockIdx.x] = dg_r0;
+                p.diag[16 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+                uint32_t xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                p.diag[16 + 4 * blockIdx.x + 2] = xcc & 7u;
+                p.diag[16 + 4 * blockIdx.x + 3] = dg_units;
+            }
+        }
+    }
+#endif
+    if (p.xq && threadIdx.x == 0) {
+        // every queue was empty when this block looked last; the block that leaves last re-zeroes the heads for the next launch
+        const uint32_t gone = __hip_atomic_fetch_add(&p.xq_heads[32 * XQ_SLICES], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == gridDim.x - 1u) {
+#pragma unroll
+            for (int q = 0; q <= XQ_SLICES; ++q) __hip_atomic_store(&p.xq_heads[32 * q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     if (MODE == HM_MODE_TOPK) {
         // one 64-bit atomic per wave for the sure count
@@ -666,10 +886,11 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
 template <int NG, int SIGN, int MODE, int BF, int TM, int WPB, int SUB>
 static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1)
 {
-    const size_t tile_bytes = (size_t)32 * SUB * (BF ? (32 * NG + 16) : 4 * hm_row_floats(NG));
+    const size_t row_bytes = BF ? 16 * hm_row16_chunks(NG) : 4 * hm_row_floats(NG);
+    const size_t tile_bytes = (size_t)32 * SUB * row_bytes;
     const size_t ppw = (tile_bytes / 1024 + WPB - 1) / WPB;
     size_t lds = ((BF ? HM_DIST_BF16 : 1) + 1) * ppw * WPB * 1024;
-    lds += (size_t)32 * (BF ? (32 * NG + 16) : 4 * hm_row_floats(NG));     // slack behind the ring: the early request of "the next group's" fragment
+    lds += (size_t)32 * row_bytes;                                          // slack behind the ring: the early request of "the next group's" fragment
     if (MODE == HM_MODE_HIST) lds += sizeof(uint32_t) * HM_HIST_BINS;      // (HIST mode keeps its bins there; they are only read by that request)
     const void* fn = reinterpret_cast<const void*>(&hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>);
     if (lds > 48 * 1024 && e->attr_done.find(fn) == e->attr_done.end()) {     // per engine (= per device), not process-wide
@@ -680,24 +901,17 @@ static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, h
     // timed launches carry their events in the dispatch itself (start / stop timestamps of this kernel): a pair of
     // hipEventRecord calls around it costs two ~6 us bubbles on the stream
     ScanArgs b = a;
-    if (MODE != HM_MODE_HIST && e->persist && a.col_begin == 0) {
-        // resident grid, equal shares of the tile sequence (see the kernel's work loop)
-        constexpr int block_rows = 32 * TM * WPB, cols = 32 * SUB, tpr = block_rows / cols;
-        const long long nrb = (a.row_end - 1) / block_rows - a.rb_first + 1;
-        b.persist = 1;
-        b.n_rb = (int)nrb;
-        b.p_total = nrb * a.nct - (long long)tpr * ((long long)a.rb_first * nrb + nrb * (nrb - 1) / 2);
+    if (MODE != HM_MODE_HIST && a.xq) {
+        // XCD-sliced unit queues (see the kernel's work loop): the grid is the blocks that are resident at once
         auto it = e->occupancy.find(fn);
         int per_cu = 0;
         if (it == e->occupancy.end()) {
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WPB, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WPB, lds + 8) != hipSuccess || per_cu < 1) per_cu = 1;
             e->occupancy[fn] = per_cu;
-            if (getenv("HM_TUNE_VERBOSE")) fprintf(stderr, "[hypmerge] scan kernel TM=%d WPB=%d lds=%zu: %d resident block(s) per CU, %d CUs\n", TM, WPB, lds, per_cu, e->n_cu);
         } else per_cu = it->second;
-        if (e->persist > 1) per_cu = e->persist - 1;                      // HM_TUNE_PERSIST = 1 + blocks per CU: override
-        const long long resident = (long long)e->n_cu * per_cu;
-        grid = dim3((unsigned)std::max<long long>(1, std::min(resident, b.p_total / 4)), 1, 1);
-    }
+        const long long units = 8ll * a.n_rb;
+        grid = dim3((unsigned)std::max<long long>(1, std::min<long long>((long long)e->n_cu * per_cu, units)), 1, 1);
+    } else b.xq = 0;
     if (ev0 != nullptr) hipExtLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, ev0, ev1, 0, b);
     else hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, b);
     return hipGetLastError();
@@ -734,16 +948,17 @@ bool hm_use_bf16(const hm_engine* e)
 #define HM_SCAN_ALL_SHAPES 0
 #endif
 #define HM_BF16_CASES(TMv, WPBv)                                                                                           \
-    switch (e->KS) {                                                                                                       \
+    switch (e->KC) {                                                                                                       \
         HM_BF16_SMALL(TMv, WPBv)                                                                                           \
-        case 7: return hm_launch_scan_ng<7, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);      \
+        case 13: return hm_launch_scan_ng<13, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);    \
     }                                                                                                                      \
     return hipErrorInvalidValue;
 #if HM_SCAN_INSTANTIATE_ALL
 #define HM_BF16_SMALL(TMv, WPBv)                                                                                           \
-        case 1: return hm_launch_scan_ng<1, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);      \
         case 2: return hm_launch_scan_ng<2, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);      \
-        case 4: return hm_launch_scan_ng<4, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+        case 4: return hm_launch_scan_ng<4, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);      \
+        case 8: return hm_launch_scan_ng<8, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);      \
+        case 14: return hm_launch_scan_ng<14, 1, TMv, WPBv, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
 #else
 #define HM_BF16_SMALL(TMv, WPBv)
 #endif
@@ -757,9 +972,9 @@ hipError_t hm_launch_scan(hm_engine* e, int mode, const ScanArgs& a, dim3 grid, 
     if (a.bf16 && a.shape == 4) { HM_BF16_CASES(3, 4) }
 #endif
     if (a.bf16) {
-        if (e->KS == 8) {
+        if (e->KC == 16) {
 #if HM_SCAN_INSTANTIATE_ALL
-            return hm_launch_scan_ng<8, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
+            return hm_launch_scan_ng<16, 1, 2, 4, HM_SUB_BF16>(e, e->sign_mode, mode, a, grid, s, ev0, ev1);
 #else
             return hipErrorInvalidValue;
 #endif
@@ -803,9 +1018,9 @@ bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t r
     // large launches: 512-row blocks halve the L2 -> LDS fill traffic, which is what limits the bf16 form once the
     // launch tail no longer does (decided by the pairs this launch covers: a row-range search of a sharded run is
     // a small launch)
-    // (KS = 8 would not fit the registers of the 128-row waves)
-    a.shape = (a.bf16 && e->KS <= 7 && hm_pairs_in_range(n, row_begin, row_end) >= e->big_min_rows * (e->big_min_rows - 1) / 2) ? 1 : 0;
-    if (a.bf16 && e->KS <= 7 && e->force_shape >= 0) a.shape = e->force_shape;
+    // (16 chunks would not fit the registers of the 128-row waves)
+    a.shape = (a.bf16 && e->KC <= 14 && hm_pairs_in_range(n, row_begin, row_end) >= e->big_min_rows * (e->big_min_rows - 1) / 2) ? 1 : 0;
+    if (a.bf16 && e->KC <= 14 && e->force_shape >= 0) a.shape = e->force_shape;
     static const int kShapeRows[5] = {256, 512, 512, 1024, 384};
     const int block_rows = a.bf16 ? kShapeRows[a.shape] : 256;
     const int cols = 32 * (a.bf16 ? HM_SUB_BF16 : HM_SUB_F32);     // partner rows per streamed tile
@@ -861,5 +1076,12 @@ bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t r
     a.n_items_a = (rb_split - a.rb_first) * a.chunks_a;
     const int n_items_b = (rb_last + 1 - rb_split) * a.chunks_b;
     grid = dim3((unsigned)std::max(1, a.n_items_a + n_items_b), 1, 1);
+    // large launches: XCD-sliced unit queues instead of the static item list (hm_launch_scan_t sizes that grid)
+    a.xq = (e->xq_min_pairs > 0 && hm_pairs_in_range(n, row_begin, row_end) >= e->xq_min_pairs) ? 1 : 0;
+    a.n_rb = nrb;
+    a.xq_heads = e->d_xq;
+#if defined(HM_DIAG_STAMPS)
+    a.diag = reinterpret_cast<unsigned long long*>(e->d_xq + 32 * 9);
+#endif
     return true;
 }

@@ -18,7 +18,7 @@ struct TailArgs {
     uint32_t cap;
     float* img;
     unsigned char* img16;
-    int RS, d, KS, sign_mode;
+    int RS, d, KC, sign_mode;
     float sqrt_c, thr;
     ArgminPart* parts;
     uint32_t* ticket;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
             const float w = (float)((double)lj / (double)(li + lj));     // len(tj) / (len(ti) + len(tj)), hyperbolic_merge.py:317-323
             hm_wave_stage_rows(a.img, a.RS, a.d, bi, bj, ms, lane);
             const float r2 = hm_wave_midpoint(a.d, w, a.mf.c, a.sign_mode, ms, true, lane);
-            hm_wave_store_row(ms, r2, a.d, a.RS, a.KS, a.mf.X, a.mf.ld, a.img, a.img16, a.mf.new_row, a.rmax2_bits, lane);
+            hm_wave_store_row(ms, r2, a.d, a.RS, a.KC, a.mf.X, a.mf.ld, a.img, a.img16, a.mf.new_row, a.rmax2_bits, lane);
             if (lane == 0) {
                 a.mf.len_rw[a.mf.new_row] = li + lj;
                 if (loop) loop->steps_done += 1u;
@@ -161,12 +161,12 @@ int hm_launch_argmin_tail(hm_engine* e, const ScanArgs& sa, float sqrt_c, float 
     TailArgs t;
     memset(&t, 0, sizeof(t));
     t.ent = e->ent; t.ctr64 = e->d_ctr64; t.cap = e->ent_cap;
-    t.img = e->img; t.img16 = e->img16; t.RS = e->RS; t.d = e->d; t.KS = e->KS; t.sign_mode = e->sign_mode;
+    t.img = e->img; t.img16 = e->img16; t.RS = e->RS; t.d = e->d; t.KC = e->KC; t.sign_mode = e->sign_mode;
     t.sqrt_c = sqrt_c; t.thr = thr;
     t.parts = e->d_parts; t.ticket = e->d_ctr + 6;
     t.out = rec_out; t.out2 = (rec_out == e->d_rec) ? e->d_rec + 1 : nullptr;
     t.seed = with_seed ? e->d_seed : nullptr;
-    t.bf = sa.bf16; t.kterms = sa.bf16 ? 16 * e->KS : e->RS; t.rmax2_bits = e->d_rmax2;
+    t.bf = sa.bf16; t.kterms = sa.bf16 ? 8 * e->KC : e->RS; t.rmax2_bits = e->d_rmax2;
     t.arm = arm ? 1 : 0; t.arm_rb = arm_rb; t.arm_re = arm_re;
     t.mf = mf;
     hipLaunchKernelGGL(hm_argmin_tail_kernel, dim3(HM_TAIL_BLOCKS), dim3(HM_TAIL_THREADS), 0, s, t);

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HM_ABI_VERSION 2
+#define HM_ABI_VERSION 3
 
 #define HM_OK            0
 #define HM_E_ARG        (-1)   /* bad argument (null pointer, range, unsupported dimension) */
@@ -285,6 +285,15 @@ int hm_scan_totals(hm_engine* e, double* scan_ms, int64_t* pairs, int64_t* launc
 /* Test hook: pretend the previous refresh ended on this emission cut (bits of u'); the next whole-table top-k
  * search starts from it as given and has to notice by itself when it is too tight. */
 int hm_debug_force_cut(hm_engine* e, uint32_t cut_bits, int64_t k, float c);
+
+/* Test / tuning hook for the pair scan's work decomposition (results never depend on it): "big_rows" (512-row blocks for
+ * launches covering at least the pairs of this many rows), "xq_pairs" (XCD-sliced unit queues for launches of at least
+ * this many pairs; 0 = never), "chunk", "tail", "tail_div", "shape", "incr_topk", "kc_even" (default knob only: bf16 image rows
+ * padded to whole 16-slot k-steps).  hm_debug_set_default_knob applies to every
+ * engine created afterwards in this process (clear != 0 removes the default `name`, or all of them when name is NULL / "").
+ * The shipped library reads no environment variable for these; tuning builds (-DHM_TUNING) also accept HM_TUNE_<NAME>. */
+int hm_debug_set_knob(hm_engine* e, const char* name, double value);
+int hm_debug_set_default_knob(const char* name, double value, int clear);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.load()
     for name in _header_functions():
         assert hasattr(L, name), name
-    assert L.hm_abi_version() == 2
+    assert L.hm_abi_version() == 3
 
 
 def test_engine_creation_fails_loudly_without_gpu():

@@ -16,18 +16,22 @@ from hyptokenizer_amd.synthetic import lorentz_table  # noqa: E402
 MODES = {"reference": 0, "lorentz": 1}
 
 
-@pytest.fixture(params=["f32", "bf16", "bf16-512"], autouse=True)
+@pytest.fixture(params=["f32", "bf16", "bf16-512", "bf16-xq", "f32-xq"], autouse=True)
 def prefilter_form(request, monkeypatch):
-    """Every test in this module runs three times: exact fp32 MFMA prefilter, bf16 MFMA prefilter, and
-    the bf16 prefilter in its large-table shape (512-row blocks, forced here at every size; both knobs
-    are read when an engine is created).  Results must be identical: the prefilter only selects
-    survivors, the canonical arithmetic decides."""
+    """Every test in this module runs five times: exact fp32 MFMA prefilter, bf16 MFMA prefilter, the bf16
+    prefilter in its large-table shape (512-row blocks, forced here at every size), and both forms with the
+    large-launch work distribution (XCD-sliced unit queues) forced at every size -- `hm_debug_set_default_knob`
+    applies to every engine created afterwards.  Results must be identical: the prefilter only selects
+    survivors, the canonical arithmetic decides, and the work distribution changes nothing but speed."""
+    from hyptokenizer_amd import _lib
+    L = _lib.load()
     monkeypatch.setenv("HM_SCAN_PRECISION", request.param.split("-")[0])
+    _lib.check(L.hm_debug_set_default_knob(None, 0.0, 1))
     if request.param.endswith("-512"):
-        monkeypatch.setenv("HM_TUNE_BIG_ROWS", "2")
-    else:
-        monkeypatch.delenv("HM_TUNE_BIG_ROWS", raising=False)
-    return request.param
+        _lib.check(L.hm_debug_set_default_knob(b"big_rows", 2.0, 0))
+    _lib.check(L.hm_debug_set_default_knob(b"xq_pairs", 1.0 if request.param.endswith("-xq") else 0.0, 0))
+    yield request.param
+    _lib.check(L.hm_debug_set_default_knob(None, 0.0, 1))
 
 
 def _engine(X, mode, max_rows=None):

@@ -18,12 +18,12 @@ def bf16_rne(x):
     return b.astype(np.uint32).view(np.float32)
 
 
-def delta_bf16(X, ksteps):
-    """the kernel's bound for the bf16 form (kterms = 16 * KS)"""
+def delta_bf16(X, kchunks):
+    """the kernel's bound for the bf16 form (kterms = 8 * KC, KC = chunks of 8 K-slots per image row)"""
     X64 = X.astype(np.float64)
     rmax2 = np.float32((X64 ** 2).sum(1).max())
     rmax2s = np.float32((X64[:, 1:] ** 2).sum(1).max())
-    d = np.float32(16 * ksteps + 8) * np.float32(1.1920929e-07) * rmax2 * np.float32(1.0001)
+    d = np.float32(8 * kchunks + 8) * np.float32(1.1920929e-07) * rmax2 * np.float32(1.0001)
     return float(d + np.float32(0.00392) * rmax2s + np.float32(3.1e-5) * rmax2)
 
 
@@ -31,8 +31,8 @@ def delta_bf16(X, ksteps):
                                             (500, 116, 0.2, 5)])
 def test_bf16_operand_rounding_stays_inside_delta(n, d, scale, seed):
     X = lorentz_table(n, d, seed=seed, scale=scale).numpy()
-    ks = (d + 4 + 15) // 16
-    delta = delta_bf16(X, ks)
+    kc = min(v for v in (2, 4, 8, 13, 14, 16) if v >= (d + 4 + 7) // 8)      # hm_pick_kc (hm_engine.hip)
+    delta = delta_bf16(X, kc)
     Xs = bf16_rne(X[:, 1:]).astype(np.float64)
     hi = bf16_rne(X[:, 0])
     lo = bf16_rne(X[:, 0] - hi)                                  # x0 ~ hi + lo
