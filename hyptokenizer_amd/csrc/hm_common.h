@@ -101,13 +101,6 @@ struct ScanArgs {
     int sample_stride;
     const uint32_t* rmax2_bits;   // [0] largest squared row norm, [1] largest squared spatial norm (float bits)
     const uint32_t* stop;         // device-resident loops: a non-zero word makes every block return at once (may be NULL)
-    // XCD-sliced unit queues (large TOPK / ARGMIN launches, hm_scan.hip): n_rb row blocks from rb_first on, one unit per
-    // (row block, slice of the column tiles); xq_heads = 9 counters on 128-byte lines (8 queue heads + blocks gone)
-    int xq, n_rb;
-    uint32_t* xq_heads;
-#if defined(HM_DIAG_STAMPS)
-    unsigned long long* diag;     // diagnostic builds: per-phase cycle sums (hm_scan.hip)
-#endif
 };
 
 // Seed of the argmin search's running key, kept on the device between searches: the key of the last
@@ -141,12 +134,9 @@ struct LoopState {
 struct hm_engine {
     int device = 0;
     int n_cu = 256;
-    // work-decomposition knobs (HM_TUNE_* environment overrides are a tuning aid)
+    // work-decomposition knobs (hm_debug_set_knob; tuning builds also read HM_TUNE_<NAME>)
     int chunk_f32 = 32, chunk_bf16 = 96, tail_div = 4;
     double tail_fraction = 0.20;
-    int64_t xq_min_pairs = 0;             // launches covering at least this many pairs use the XCD-sliced unit queues (0: never; experiment)
-    uint32_t* d_xq = nullptr;             // their 9 counters (zero between launches: the kernel's last block re-zeroes them)
-    std::map<const void*, int> occupancy;  // resident blocks per CU of each scan kernel
     int force_shape = -1;                 // HM_TUNE_SHAPE: bf16 block shape of every launch (tuning builds)
     int64_t big_min_rows = 80000;         // bf16 form: launches covering at least the pairs of this many rows use 512-row blocks
     int64_t max_rows = 0, rows_alloc = 0, n = 0;

@@ -39,7 +39,9 @@ static int hm_pick_ng(int d)
 extern "C" int hm_abi_version(void) { return HM_ABI_VERSION; }
 
 // ---- work-decomposition knobs (test / tuning hook: hm_debug_set_knob, hm_debug_set_default_knob) ----
-static const char* const kKnobNames[] = {"chunk", "tail", "tail_div", "big_rows", "shape", "incr_topk", "xq_pairs", "kc_even"};
+#if defined(HM_TUNING)
+static const char* const kKnobNames[] = {"chunk", "tail", "tail_div", "big_rows", "shape", "incr_topk", "kc_even"};
+#endif
 static std::map<std::string, double> g_default_knobs;          // applied to every engine created afterwards
 
 static int hm_apply_knob(hm_engine* e, const char* name, double v)
@@ -51,7 +53,6 @@ static int hm_apply_knob(hm_engine* e, const char* name, double v)
     else if (k == "big_rows") { if (!(v >= 0)) return HM_E_ARG; e->big_min_rows = (int64_t)v; }          // 512-row blocks from this many rows' pairs on
     else if (k == "shape") { if (!(v >= -1 && v <= 4)) return HM_E_ARG; e->force_shape = (int)v; }
     else if (k == "incr_topk") e->incremental_topk = v != 0.0;
-    else if (k == "xq_pairs") { if (!(v >= 0)) return HM_E_ARG; e->xq_min_pairs = (int64_t)v; }          // XCD-sliced queues from this many pairs on (0: never)
     else if (k == "kc_even") {            // bf16 image with an even chunk count (whole k-steps only): default knob only, before the images exist
         if (e->img16 != nullptr) return HM_E_STATE;
         if (v != 0.0 && (e->KC & 1)) { e->KC += 1; e->RB16 = 16 * hm_row16_chunks(e->KC); }
@@ -67,19 +68,6 @@ extern "C" int hm_debug_set_knob(hm_engine* e, const char* name, double value)
     const int rc = hm_apply_knob(e, name, value);
     return rc ? hm_fail(e, rc, "hm_debug_set_knob: unknown knob or value out of range") : HM_OK;
 }
-
-#if defined(HM_DIAG_STAMPS)
-// diagnostic builds: read (and clear) the per-phase cycle sums of the scans since the last call
-extern "C" int hm_diag_read(hm_engine* e, unsigned long long* out, int with_blocks)
-{
-    HM_HIP(hipSetDevice(e->device));
-    HM_HIP(hipDeviceSynchronize());
-    const size_t n = with_blocks ? (16 + 4 * 8192 + 8 * 4096) : 16;
-    HM_HIP(hipMemcpy(out, e->d_xq + 32 * 9, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HM_HIP(hipMemset(e->d_xq + 32 * 9, 0, (16 + 4 * 8192 + 8 * 4096) * sizeof(unsigned long long)));
-    return HM_OK;
-}
-#endif
 
 extern "C" int hm_debug_set_default_knob(const char* name, double value, int clear)
 {
@@ -123,13 +111,6 @@ static int hm_engine_alloc(hm_engine* e)
     HM_HIP(hipMemset(e->d_rmax2, 0, sizeof(uint32_t) * 2));
     HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 4));
     HM_HIP(hipMemset(e->d_ctr64, 0, sizeof(unsigned long long) * 4));
-#if defined(HM_DIAG_STAMPS)
-    const size_t diag_bytes = (16 + 4 * 8192 + 8 * 4096) * sizeof(unsigned long long);      // phase sums + per-block stamps + unit log
-#else
-    const size_t diag_bytes = 0;
-#endif
-    HM_HIP(hipMalloc(&e->d_xq, sizeof(uint32_t) * 32 * 9 + diag_bytes));
-    HM_HIP(hipMemset(e->d_xq, 0, sizeof(uint32_t) * 32 * 9 + diag_bytes));
     HM_HIP(hipMalloc(&e->d_seed, sizeof(ArgminSeed)));
     HM_HIP(hipMemset(e->d_seed, 0, sizeof(ArgminSeed)));
     HM_HIP(hipMalloc(&e->d_rec, 2 * sizeof(ArgminRec)));
@@ -216,7 +197,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
     void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts,
-                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch, e->d_xq};
+                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch};
     for (void* q : dev_ptrs)
         if (q) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);

@@ -16,20 +16,21 @@ from hyptokenizer_amd.synthetic import lorentz_table  # noqa: E402
 MODES = {"reference": 0, "lorentz": 1}
 
 
-@pytest.fixture(params=["f32", "bf16", "bf16-512", "bf16-xq", "f32-xq"], autouse=True)
+@pytest.fixture(params=["f32", "bf16", "bf16-512", "bf16-k112"], autouse=True)
 def prefilter_form(request, monkeypatch):
-    """Every test in this module runs five times: exact fp32 MFMA prefilter, bf16 MFMA prefilter, the bf16
-    prefilter in its large-table shape (512-row blocks, forced here at every size), and both forms with the
-    large-launch work distribution (XCD-sliced unit queues) forced at every size -- `hm_debug_set_default_knob`
+    """Every test in this module runs four times: exact fp32 MFMA prefilter, bf16 MFMA prefilter, the bf16
+    prefilter in its large-table shape (512-row blocks, forced here at every size), and the bf16 prefilter on image
+    rows padded to whole 16-slot k-steps (d = 100: 14 chunks instead of 13 + a half step) -- `hm_debug_set_default_knob`
     applies to every engine created afterwards.  Results must be identical: the prefilter only selects
-    survivors, the canonical arithmetic decides, and the work distribution changes nothing but speed."""
+    survivors, the canonical arithmetic decides."""
     from hyptokenizer_amd import _lib
     L = _lib.load()
     monkeypatch.setenv("HM_SCAN_PRECISION", request.param.split("-")[0])
     _lib.check(L.hm_debug_set_default_knob(None, 0.0, 1))
     if request.param.endswith("-512"):
         _lib.check(L.hm_debug_set_default_knob(b"big_rows", 2.0, 0))
-    _lib.check(L.hm_debug_set_default_knob(b"xq_pairs", 1.0 if request.param.endswith("-xq") else 0.0, 0))
+    if request.param.endswith("-k112"):
+        _lib.check(L.hm_debug_set_default_knob(b"kc_even", 1.0, 0))
     yield request.param
     _lib.check(L.hm_debug_set_default_knob(None, 0.0, 1))
 

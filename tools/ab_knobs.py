@@ -1,6 +1,6 @@
 """Interleaved A/B timing of the pair scan under different work-decomposition knobs of ONE library build
 (`hm_debug_set_default_knob`), in one process: python tools/ab_knobs.py "name:knob=value,knob=value" ...
-e.g.  python tools/ab_knobs.py "static:xq_pairs=0" "xq:xq_pairs=1" "xq512:xq_pairs=1,big_rows=2"
+e.g.  python tools/ab_knobs.py "s256:big_rows=1000000" "s512:big_rows=2" "k112:kc_even=1"
 AB_V / AB_D select the table, AB_MODE = argmin | topk."""
 import os, sys, statistics, torch
 sys.path.insert(0, ".")

@@ -12,13 +12,13 @@ bad = 0
 for t in range(cases):
     n = int(rng.integers(2, 3500)); d = int(rng.choice([1, 2, 3, 5, 8, 10, 16, 23, 24, 31, 50, 64, 77, 100, 112, 124, 125, 128]))
     scale = float(rng.choice([0.01, 0.05, 0.05, 0.2, 1.0])); mode = str(rng.choice(["lorentz", "lorentz", "reference"]))
-    form = str(rng.choice(["f32", "bf16", "bf16-512", "bf16-xq", "f32-xq", "bf16-512-xq"])); c = float(rng.choice([1.0, 1.0, 0.3, 4.0]))
+    form = str(rng.choice(["f32", "bf16", "bf16-512", "bf16-k112", "bf16-512-k112"])); c = float(rng.choice([1.0, 1.0, 0.3, 4.0]))
     os.environ["HM_SCAN_PRECISION"] = form.split("-")[0]
     from hyptokenizer_amd import _lib
     _L = _lib.load()
     _L.hm_debug_set_default_knob(None, 0.0, 1)
     if "512" in form: _L.hm_debug_set_default_knob(b"big_rows", 2.0, 0)
-    _L.hm_debug_set_default_knob(b"xq_pairs", 1.0 if form.endswith("xq") else 0.0, 0)
+    if form.endswith("k112"): _L.hm_debug_set_default_knob(b"kc_even", 1.0, 0)
     X = lorentz_table(n, d, seed=int(rng.integers(1 << 30)), scale=scale)
     if rng.random() < 0.2 and n > 10:                     # a few exact duplicates
         X[rng.integers(n, size=3)] = X[rng.integers(n, size=3)]
