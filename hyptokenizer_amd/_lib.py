@@ -19,7 +19,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HYPMERGE_LIB") or os.path.join(_HERE, "libhypmerge.so")
 
 HM_OK = 0
-HM_E_ARG, HM_E_CAPACITY, HM_E_STATE, HM_E_NOMEM = -1, -2, -3, -4
+HM_E_ARG, HM_E_CAPACITY, HM_E_STATE, HM_E_NOMEM, HM_E_COMM = -1, -2, -3, -4, -5
+COMM_ID_BYTES = 128
 SIGN_REFERENCE, SIGN_LORENTZ = 0, 1
 PREFILTER_AUTO, PREFILTER_F32, PREFILTER_BF16 = 0, 1, 2
 LOOP_MAX_STEPS = 256
@@ -35,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "hm_coherence_batch", "hm_project_table", "hm_debug_force_cut", "hm_randperm_prefix", "hm_merge_append_batch_host",
     "hm_tokenize_table_capacity", "hm_tokenize_build_table", "hm_tokenize_batch", "hm_debug_time_loops", "hm_last_loop_timing", "hm_shard_loop_begin", "hm_shard_merge_step", "hm_shard_loop_end",
     "hm_topk_refresh_begin", "hm_topk_refresh_end", "hm_debug_set_knob", "hm_debug_set_default_knob",
+    "hm_comm_unique_id", "hm_comm_init", "hm_comm_destroy", "hm_comm_info", "hm_shard_merge_steps", "hm_global_argmin", "hm_global_topk",
 )
 
 
@@ -98,6 +100,13 @@ def load() -> C.CDLL:
     L.hm_tokenize_table_capacity.argtypes = [i64]
     L.hm_tokenize_build_table.argtypes = [vp, vp, vp, i64, vp, i64]
     L.hm_tokenize_batch.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp, vp]
+    L.hm_comm_unique_id.argtypes = [vp]
+    L.hm_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.hm_comm_destroy.argtypes = [vp]
+    L.hm_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.hm_shard_merge_steps.argtypes = [vp, f32, f32, vp, i64, i64, vp, pi64, vp]
+    L.hm_global_argmin.argtypes = [vp, f32, f32, pf32, pi32, pi32, pi32, vp]
+    L.hm_global_topk.argtypes = [vp, f32, f32, i64, vp, vp, vp, pi64, pi64, vp]
     L.hm_debug_set_knob.argtypes = [vp, C.c_char_p, C.c_double]
     L.hm_debug_set_default_knob.argtypes = [C.c_char_p, C.c_double, C.c_int]
     L.hm_engine_destroy.argtypes = [vp]

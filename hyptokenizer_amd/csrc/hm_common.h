@@ -195,6 +195,13 @@ struct hm_engine {
     // row-sharded device-resident loop (hm_shard_loop_begin .. _end): searches skip themselves once the loop has stopped
     bool shard_loop = false;
     int64_t shard_n0 = 0;
+    // RCCL communicator bound by hm_comm_init (hm_comm.hip): opaque ncclComm_t, this rank, ranks, exchange buffers
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+    ArgminRec* d_shard_rec = nullptr;      // this rank's record of a step
+    ArgminRec* d_shard_recs = nullptr;     // gathered records: HM_LOOP_MAX_STEPS x world
+    uint4* d_gather = nullptr;             // refresh: this rank's packed list [k + 1], then the gathered lists [world][k + 1]
+    hipEvent_t step_ev0 = nullptr, step_ev1 = nullptr;   // set around hm_pairwise_argmin_dev by the in-library sharded loop's timing mode
     // hm_debug_time_loops: an event pair around EVERY scan of a device-resident batch and around the batch itself
     bool time_loops = false;
     std::vector<hipEvent_t> loop_evs;     // 2 * HM_LOOP_MAX_STEPS + 2, created on first use
@@ -460,5 +467,7 @@ __device__ __forceinline__ uint32_t hm_wave_incl_scan(uint32_t v, int lane)
 }
 
 // ---- hm_search.hip (host) ----
+int hm_select_sorted(hm_engine* e, uint4* src, uint4* other, uint32_t m, uint32_t k, hipStream_t s);
+void hm_partition_rows(int64_t n, int world, int rank, int64_t* r0, int64_t* r1);      // hm_comm.hip
 int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, bool list_all, bool want_count,
                  int64_t n_limit, int64_t* n_valid_emitted, int64_t* count, uint4** result_dev, hipStream_t s);

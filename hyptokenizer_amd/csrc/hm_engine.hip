@@ -196,6 +196,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
 {
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
+    (void)hm_comm_destroy(e);
     void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts,
                         e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch};
     for (void* q : dev_ptrs)

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void hm_rank_merge_dev_kernel(const uint4* __r
 
 // exact selection of the k smallest keys among m entries of `src` (keys unique; invalid = 0xffffffff)
 // result in e->sorted.  `other` is scratch of the same capacity.
-static int hm_select_sorted(hm_engine* e, uint4* src, uint4* other, uint32_t m, uint32_t k, hipStream_t s)
+int hm_select_sorted(hm_engine* e, uint4* src, uint4* other, uint32_t m, uint32_t k, hipStream_t s)
 {
     if (k == 0 || m == 0) return HM_OK;
     if (k > e->sorted_cap) return hm_fail(e, HM_E_CAPACITY, "top-k: k exceeds the engine's sorted capacity (65536)");
@@ -757,10 +757,13 @@ extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t 
         a.stop = &e->d_loop->stop;
         mf.loop = e->d_loop;
     }
-    // (inside a sharded loop only the batch's first search carries timing events: reading them back at the next call is a
-    // host wait, and the point of the loop is that the host runs ahead of the device)
-    const bool timed = !e->shard_loop || e->n == e->shard_n0;
-    HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, timed ? e->ev0 : nullptr, timed ? e->ev1 : nullptr));
+    // (inside a sharded loop only the batch's first search carries the engine's own timing events: reading them back at the
+    // next call is a host wait, and the point of the loop is that the host runs ahead of the device; the in-library loop in
+    // its measurement mode hands every step its own pair -- e->step_ev0 / _ev1, read after the batch)
+    const bool step_timed = e->step_ev0 != nullptr;
+    const bool timed = !step_timed && (!e->shard_loop || e->n == e->shard_n0);
+    HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, step_timed ? e->step_ev0 : (timed ? e->ev0 : nullptr),
+                          step_timed ? e->step_ev1 : (timed ? e->ev1 : nullptr)));
     int rc = hm_launch_argmin_tail(e, a, sqrtf(c), thr, reinterpret_cast<ArgminRec*>(rec_dev), true, (int)req_rb,
                                    req_re < 0 ? 0x7fffffff : (int)std::min<int64_t>(req_re, 0x7fffffff), true, mf, s);
     if (rc) return rc;

@@ -312,6 +312,59 @@ class MergeEngine:
         self._chk(self._L.hm_shard_loop_end(self._h, int(steps), _np_ptr(self._rec_buf), C.byref(done), self._stream()))
         return self._unpack(int(steps)), int(done.value)
 
+    # -- the exchange step inside the library (RCCL communicator bound to the engine) -----------------------
+    def comm_init(self, group=None) -> None:
+        """Bind an RCCL communicator of the ranks of ``group`` (a ``torch.distributed`` group of any backend: it only
+        carries the 128-byte id from rank 0 to the others) to this engine.  Collective: every rank calls it."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_ubyte * _lib.COMM_ID_BYTES)()
+            _lib.check(self._L.hm_comm_unique_id(buf))
+            ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+        gdev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        ident = ident.to(gdev)
+        dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(ident.cpu().numpy().tobytes())
+        with torch.cuda.device(self.device):
+            self._chk(self._L.hm_comm_init(self._h, C.c_char_p(raw), int(rank), int(world)))
+
+    def comm_info(self):
+        """(rank, world) of the bound communicator, or None."""
+        r, w = C.c_int(-1), C.c_int(0)
+        self._L.hm_comm_info(self._h, C.byref(r), C.byref(w))
+        return (int(r.value), int(w.value)) if w.value > 0 else None
+
+    def comm_destroy(self) -> None:
+        self._chk(self._L.hm_comm_destroy(self._h))
+
+    def shard_merge_steps(self, c: float, thr: float, table: torch.Tensor, steps: int):
+        """``steps`` (<= 256) iterations of the row-sharded standard loop, enqueued by the library: per step the scan of
+        this rank's rows, the all-gather of the records (RCCL) and the merge -> (records, done), identical on every rank."""
+        t = self._check_table(table)
+        done = C.c_int64(0)
+        self._chk(self._L.hm_shard_merge_steps(self._h, _f(c), float(thr), _ptr(t), t.stride(0), int(steps),
+                                               _np_ptr(self._rec_buf), C.byref(done), self._stream()))
+        return self._unpack(int(steps)), int(done.value)
+
+    def global_argmin(self, c: float, thr: float) -> Optional[Tuple[float, int, int]]:
+        """Nearest pair of the whole table through the bound communicator (collective)."""
+        d, i, j, f = C.c_float(0), C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
+        self._chk(self._L.hm_global_argmin(self._h, _f(c), float(thr), C.byref(d), C.byref(i), C.byref(j), C.byref(f), self._stream()))
+        return (float(d.value), int(i.value), int(j.value)) if f.value else None
+
+    def global_topk(self, c: float, thr: float, k: int):
+        """k smallest candidates of the whole table in order and their exact number (collective): the ranks' lists are
+        gathered and merged on the device."""
+        k = int(k)
+        d, i, j = np.empty(k, np.float32), np.empty(k, np.int32), np.empty(k, np.int32)
+        n_out, total = C.c_int64(0), C.c_int64(0)
+        self._chk(self._L.hm_global_topk(self._h, _f(c), float(thr), k, _np_ptr(d), _np_ptr(i), _np_ptr(j), C.byref(n_out),
+                                         C.byref(total), self._stream()))
+        m = int(n_out.value)
+        return d[:m], i[:m], j[:m], int(total.value)
+
     def debug_time_loops(self, on: bool) -> None:
         """Measurement aid: event pairs around every scan of the following ``std_merge_steps`` batches."""
         self._chk(self._L.hm_debug_time_loops(self._h, 1 if on else 0))

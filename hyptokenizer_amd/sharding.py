@@ -87,6 +87,20 @@ class ShardContext:
             self._host = self._host.pin_memory()
         self._rec_dev = {}          # engine device -> int32[4] record the engine writes (always device memory)
 
+    def bind_engine(self, engine) -> bool:
+        """With an RCCL ("nccl") group and an engine on this rank's GPU, bind a communicator of the group's ranks to the
+        engine (once; collective -- every rank reaches this at the same point of the same loop) so that the exchange step
+        runs inside the library: ``hm_shard_merge_steps`` / ``hm_global_argmin`` / ``hm_global_topk``.  False: the group is
+        a CPU one (tests, ranks sharing a GPU) and the exchange stays with ``torch.distributed`` in Python."""
+        if dist.get_backend(self.group) != "nccl" or not hasattr(engine, "comm_init"):
+            return False
+        edev = getattr(engine, "device", None)
+        if edev is None or edev.type != "cuda" or edev != self.device:
+            return False
+        if engine.comm_info() is None:
+            engine.comm_init(self.group)
+        return True
+
     def record_buffer(self, device: torch.device) -> torch.Tensor:
         """The 16-byte record an engine on `device` writes with ``argmin_into`` (allocated once per device)."""
         key = str(device)
@@ -159,6 +173,8 @@ def sharded_argmin(engine, ctx: ShardContext, c: float, thr: float):
     scan -> record in HBM -> all-gather on the same stream -> one 16*world-byte read-back (RCCL, backend "nccl"), or
     record -> host -> all-gather over the CPU backend (gloo: tests, ranks that share a GPU).  The same engine code
     path (armed / seeded searches, overflow reports, row ranges that move as the table grows) either way."""
+    if ctx.bind_engine(engine):
+        return engine.global_argmin(c, thr)
     r0, r1 = ctx.row_range(engine.n)
     edev = getattr(engine, "device", None)
     if hasattr(engine, "argmin_into") and edev is not None and edev.type == "cuda":
@@ -192,6 +208,10 @@ def _best_of_records(recs: np.ndarray):
 
 
 def sharded_topk(engine, ctx: ShardContext, c: float, thr: float, k: int):
+    """Global ordered top-k and exact count.  RCCL group: the ranks' lists never leave the device (``hm_global_topk``);
+    CPU group: gathered as numpy arrays through ``torch.distributed``."""
+    if ctx.bind_engine(engine):
+        return engine.global_topk(c, thr, k)
     r0, r1 = ctx.row_range(engine.n)
     d, i, j, cnt = engine.topk(c, thr, k, r0, r1)
     return ctx.global_topk(d, i, j, cnt, k)

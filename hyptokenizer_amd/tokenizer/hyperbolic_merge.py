@@ -378,6 +378,8 @@ class HyperbolicTokenizer:
         import torch.distributed as dist
         from ..sharding import partition_rows
         ctx = self.shard
+        if ctx.bind_engine(eng):                  # RCCL group: the whole batch is enqueued by the library (hm_shard_merge_steps)
+            return eng.shard_merge_steps(self.curvature, thr, self.embeddings.data, k)
         n0 = self.current_vocab_size
         dev = eng.device
         rec = ctx.record_buffer(dev)

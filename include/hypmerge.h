@@ -40,6 +40,7 @@ extern "C" {
 #define HM_E_CAPACITY   (-2)   /* an internal workspace was too small for this request      */
 #define HM_E_STATE      (-3)   /* call order violated (e.g. scan before hm_set_table)        */
 #define HM_E_NOMEM      (-4)
+#define HM_E_COMM       (-5)   /* RCCL could not be loaded / a collective failed            */
 
 #define HM_SIGN_REFERENCE 0
 #define HM_SIGN_LORENTZ   1
@@ -195,6 +196,31 @@ int hm_shard_loop_begin(hm_engine* e, void* stream);
 int hm_shard_merge_step(hm_engine* e, const uint32_t* recs_dev, int world, float c, float* X_dev, int64_t ld, int64_t step,
                         void* stream);
 int hm_shard_loop_end(hm_engine* e, int64_t steps, uint32_t* rec_out, int64_t* done, void* stream);
+
+/* ---- the exchange step inside the library (hm_comm_init, hm_global_argmin, hm_global_topk) ----
+ * One process per GPU; every rank holds a replica of the table and an engine of its own.  hm_comm_unique_id (one rank)
+ * produces the 128-byte RCCL id the host program hands to the other ranks by its own means (torch.distributed broadcast,
+ * MPI, a file); hm_comm_init binds an RCCL communicator (over xGMI on one node) to the engine; collective calls below must
+ * then be made by every rank with the same arguments.  librccl.so.1 is bound at run time (the copy already loaded by the
+ * process when there is one): HM_E_COMM when it is missing.  Rows are cut into `world` ranges of equal pair count.
+ * Replaces: nothing in the reference (single process); the loop sharded is hyperbolic_merge.py:357-412. */
+#define HM_COMM_ID_BYTES 128
+int hm_comm_unique_id(void* id_out128);
+int hm_comm_init(hm_engine* e, const void* id128, int rank, int world);
+int hm_comm_destroy(hm_engine* e);
+int hm_comm_info(const hm_engine* e, int* rank, int* world);          /* rank = -1, world = 0 without a communicator */
+/* `steps` (<= 256) iterations of the standard loop, row-sharded, enqueued from the library with no host code per step:
+ * scan of this rank's rows -> record -> ncclAllGather (16 bytes per rank) -> global minimum + merge into this rank's
+ * replica.  Records / *done as hm_std_merge_steps (identical on every rank). */
+int hm_shard_merge_steps(hm_engine* e, float c, float thr, float* X_dev, int64_t ld, int64_t steps, uint32_t* rec_out,
+                         int64_t* done, void* stream);
+/* C1: the global nearest pair (search of this rank's rows, all-gather of the records, minimum).  Host results. */
+int hm_global_argmin(hm_engine* e, float c, float thr, float* d, int32_t* i, int32_t* j, int32_t* found, void* stream);
+/* C2: the k smallest candidates of the whole table in order and their exact number: every rank's ordered list of its rows
+ * stays on the device, the lists are all-gathered and merged there by the exact selection (no host round trip of the
+ * lists).  Arguments as hm_pairwise_topk without the row range. */
+int hm_global_topk(hm_engine* e, float c, float thr, int64_t k, float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out,
+                   int64_t* count, void* stream);
 
 /* Measurement aid: with on != 0, hm_std_merge_steps records a HIP event pair around every scan launch of a batch (all of
  * them enter hm_scan_totals) and around the whole batch; hm_last_loop_timing returns the last batch's wall time on the

@@ -275,6 +275,43 @@ def test_device_record_and_world1_nccl_shard(oracle):
             runs.append((list(tok.merge_history), tok.embeddings.data[n:n + 40].cpu(), list(ftok.merge_history)))
         assert runs[0][0] == runs[1][0] and runs[0][2] == runs[1][2]
         assert torch.equal(runs[0][1].view(torch.int32), runs[1][1].view(torch.int32))      # bits: NaN rows included
+        # the sharded runs went through the library's own exchange step (hm_comm_init + hm_shard_merge_steps / hm_global_topk)
+        assert tok._engine.comm_info() == (0, 1) and ftok._engine.comm_info() == (0, 1)
+        # ... whose one-shot forms equal the single-process searches, and whose loop equals the single-process loop
+        eng.comm_init()
+        assert eng.comm_info() == (0, 1)
+        for thr in (0.3, 0.25, 1e-9):
+            assert eng.global_argmin(1.0, thr) == eng.argmin(1.0, thr)
+            gd, gi, gj, gc = eng.global_topk(1.0, thr, 300)
+            hd, hi, hj, hc = eng.topk(1.0, thr, 300)
+            assert gc == hc and np.array_equal(gi, hi) and np.array_equal(gj, hj) and np.array_equal(bits(gd), bits(hd))
+        od, oi, oj, oc = oracle.pairwise_topk(X.numpy(), n, 1.0, 0.3, 1, 300)
+        gd, gi, gj, gc = eng.global_topk(1.0, 0.3, 300)
+        assert gc == oc and np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(bits(gd), bits(od))
+        t_a, t_b = table.clone(), table.clone()
+        eng_b = MergeEngine(n + 64, d + 1, "lorentz")
+        eng_b.set_table(t_b, n)
+        eng.set_table(t_a, n)
+        lens = np.ones(n, np.int32)
+        eng.set_token_lengths(lens)
+        eng_b.set_token_lengths(lens)
+        eng.debug_time_loops(True)
+        ra, da = eng.shard_merge_steps(1.0, 0.3, t_a, 24)
+        rb, db = eng_b.std_merge_steps(1.0, 0.3, t_b, 24)
+        assert da == db == 24 and [r[2:] for r in ra] == [r[2:] for r in rb] and [bits([r[1]])[0] for r in ra] == [bits([r[1]])[0] for r in rb]
+        assert torch.equal(t_a.view(torch.int32), t_b.view(torch.int32))
+        tm = eng.last_loop_timing()
+        assert tm["steps"] == 24 and 0 < tm["scan_ms"] < tm["batch_ms"]         # every scan of the sharded batch carried its events
+        # a loop that runs out of candidates stops on the device in the sharded form too
+        t_c = table.clone()
+        eng.set_table(t_c, n)
+        dmin = eng.argmin(1.0, 10.0)[0]
+        ra, da = eng.shard_merge_steps(1.0, dmin, t_c, 5)                       # nothing is strictly below the nearest distance
+        assert da == 0 and ra[0][0] == 0 and all(r[0] == 3 for r in ra[1:])
+        ra, da = eng.shard_merge_steps(1.0, 0.0, t_c, 3)                        # ... nor below a non-positive threshold
+        assert da == 0 and ra[0][0] == 0 and all(r[0] == 3 for r in ra[1:])
+        eng.comm_destroy()
+        assert eng.comm_info() is None
     finally:
         dist.destroy_process_group()
 
