@@ -52,8 +52,9 @@ PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E
 
 
 def cpu_baseline(X: np.ndarray, device, budget_s: float = 12.0) -> dict:
-    """Time the oracle (CPU restatement, OpenMP) on rows [0, R) of the same search and extrapolate
-    by pair count; check that the GPU returns the identical pair for the same row range."""
+    """Time the oracle (CPU restatement, OpenMP) on rows [0, R) of the same search (any table: the headline's and the
+    V = 100 000 leg's) and extrapolate by pair count; check that the GPU returns the identical pair for the same row range."""
+    dim = X.shape[1] - 1
     from oracle import hm_oracle as O
     from hyptokenizer_amd.engine import MergeEngine
     O.build()
@@ -85,9 +86,9 @@ def cpu_baseline(X: np.ndarray, device, budget_s: float = 12.0) -> dict:
     del gpu_engine, table
     return {
         "value": 1.0 / est_scan_s, "unit": "merges/s", "cores": cores, "kind": "port",
-        "sample": f"rows [0,{rows}) of the V={n} d={D} search = {100 * frac:.1f}% of all pairs in {t:.2f} s, "
+        "sample": f"rows [0,{rows}) of the V={n} d={dim} search = {100 * frac:.1f}% of all pairs in {t:.2f} s, "
                   f"extrapolated by pair count (midpoint cost negligible)",
-        "gflops": 2.0 * pairs(rows) * (D + 1) / t / 1e9,
+        "gflops": 2.0 * pairs(rows) * (dim + 1) / t / 1e9,
         "same_pair_as_gpu_on_sample": bool(same),
         "note": "the oracle's own OpenMP restatement (the reference cannot run at this size, SURVEY F9): context, not a target",
     }
@@ -115,8 +116,9 @@ def warm_clocks(eng, ms: float = 60.0, thr: float = THR) -> None:
     torch.cuda.synchronize()
 
 
-def std_loop_leg(vocab_size, dim, prefilter, sign, steps, device, thr=THR, label=""):
-    """merges/s of the standard loop + the scan's roofline for another configuration (N = 1)"""
+def std_loop_leg(vocab_size, dim, prefilter, sign, steps, device, thr=THR, label="", with_cpu=False):
+    """merges/s of the standard loop + the scan's roofline for another configuration (N = 1); `with_cpu`: the CPU
+    baseline of the same search timed beside it, as for the headline"""
     from hyptokenizer_amd.synthetic import cjk_vocab, lorentz_table
     from hyptokenizer_amd.tokenizer.hyperbolic_merge import HyperbolicTokenizer
     X = lorentz_table(vocab_size, dim, seed=SEED, scale=SCALE)
@@ -146,6 +148,9 @@ def std_loop_leg(vocab_size, dim, prefilter, sign, steps, device, thr=THR, label
                            "frac": fl / (ms * 1e-3) / 1e12 / peak, "avg_launch_ms": ms, "timed_launches": tot["launches"],
                            "form": "bf16" if bf else "f32"}
     del tok, eng
+    if with_cpu and out["merges_per_s"]:
+        out["cpu_baseline"] = cpu_baseline(X.numpy(), device, budget_s=10.0)
+        out["speedup_vs_cpu_baseline"] = out["merges_per_s"] / out["cpu_baseline"]["value"]
     return out
 
 
@@ -455,7 +460,7 @@ def main() -> None:
     # Every scan launch of the timed region carries its own HIP event pair IN the dispatch (start / stop timestamps of that
     # kernel: no extra packets on the stream), and each device batch one pair around it: the roofline's mean launch duration
     # and the time a step spends outside the scan both come from the timed region itself.
-    timing = world == 1 and shard is None
+    timing = world == 1 or not rehearse          # (the in-library sharded loop times every scan too; the gloo rehearsal does not)
     if timing:
         eng.debug_time_loops(True)
     eng.scan_totals(reset=True)
@@ -528,7 +533,7 @@ def main() -> None:
         legs = {}
         lsteps = max(20, min(args.steps, 100))
         for key, fn in (
-            ("v100k_d100_bf16", lambda: std_loop_leg(100000, 100, "bf16", "lorentz", lsteps, device,
+            ("v100k_d100_bf16", lambda: std_loop_leg(100000, 100, "bf16", "lorentz", lsteps, device, with_cpu=not args.no_cpu_baseline,
                                                      label="V=100000 d=100 lorentz thr=0.5, bf16 prefilter (north star target size)")),
             ("v50k_d50_f32", lambda: std_loop_leg(50000, 50, "f32", "lorentz", lsteps, device,
                                                   label="V=50000 d=50 lorentz thr=0.5, fp32-MFMA prefilter (BASELINE config 2)")),
@@ -558,7 +563,7 @@ def main() -> None:
         form = os.environ.get("HM_SCAN_PRECISION", "auto")
         bf16 = form != "f32"                     # auto picks the bf16 prefilter at d = 100
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-        kernel_name = "hm_scan_kernel<KS=7,lorentz,ARGMIN,bf16>" if bf16 else "hm_scan_kernel<NG=25,lorentz,ARGMIN,fp32>"
+        kernel_name = "hm_scan_kernel<13 chunks,lorentz,ARGMIN,bf16>" if bf16 else "hm_scan_kernel<NG=25,lorentz,ARGMIN,fp32>"
         traffic, traffic_src = traffic_from_profiles("bf16" if bf16 else "f32") if world == 1 else (None, None)
         n_mid = V + args.warmup + args.steps / 2.0
         scan_ms_per_step = max(p[0] / max(p[2], 1.0) for p in per_rank)     # slowest rank's scan per step
