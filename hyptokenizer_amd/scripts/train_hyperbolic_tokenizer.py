@@ -2,9 +2,15 @@
 """Train a hyperbolic tokenizer on the MI355X merge engine.
 
 CLI surface of the reference's ``scripts/train_hyperbolic_tokenizer.py`` (same typer options,
-defaults, output files).  Additive options: ``--sign-convention`` (reference | lorentz) and
+defaults, output files).  Additive options: ``--sign-convention`` (reference | lorentz),
 ``--init-device`` (where the random initial tangent vectors are drawn; ``cpu`` reproduces a run of
-the reference on a CPU-only host bit for bit in the RNG stream).
+the reference on a CPU-only host bit for bit in the RNG stream) and ``--num-gpus``.
+
+Multi-GPU: launch one process per GPU (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 -m hyptokenizer_amd.scripts.train_hyperbolic_tokenizer ...``): with ``WORLD_SIZE > 1`` the
+script joins the process group (RCCL, backend "nccl", one GPU per rank by ``LOCAL_RANK``), the candidate search is
+row-sharded over the ranks (``hyptokenizer_amd.sharding``), every rank keeps an identical replica of the tokenizer
+and rank 0 alone writes the output files.  ``--num-gpus`` is a check that the launch has the intended width.
 """
 from __future__ import annotations
 
@@ -60,6 +66,35 @@ def initialize_embeddings(vocab: List[str], embedding_dim: int, curvature: float
     return project_to_hyperboloid(points, curvature)
 
 
+def _join_process_group(num_gpus: Optional[int]):
+    """Under ``torch.distributed.run`` (``WORLD_SIZE > 1``): initialise the process group BEFORE any GPU call of this
+    process -- RCCL with one GPU per rank when GPUs are visible, else gloo (CPU tests) -- and return (context, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if num_gpus is not None and num_gpus > 1 and world != num_gpus:
+        raise SystemExit(f"--num-gpus {num_gpus} needs a launch with {num_gpus} processes (python -m torch.distributed.run "
+                         f"--nproc-per-node {num_gpus} ...); WORLD_SIZE is {world}")
+    if world <= 1:
+        return None, None
+    import torch.distributed as dist
+    from hyptokenizer_amd.sharding import ShardContext
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    own = not dist.is_initialized()
+    device = None
+    if own:
+        if torch.cuda.device_count() > 0 and os.environ.get("HM_CLI_BACKEND", "") != "gloo":
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(local)
+            device = torch.device("cuda", local)
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    elif dist.get_backend() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    ctx = ShardContext(device=device)
+    ctx.owns_group = own
+    return ctx, device
+
+
 def train_tokenizer(
     vocab_path: str,
     output_dir: str,
@@ -80,11 +115,14 @@ def train_tokenizer(
     no_faiss: bool = False,
     sign_convention: str = "reference",
     init_device: Optional[str] = None,
+    num_gpus: Optional[int] = None,
 ) -> Dict[str, Any]:
-    """Reference ``:112-297``."""
+    """Reference ``:112-297``.  Row-sharded over the ranks of the launch when ``WORLD_SIZE > 1`` (every rank runs the
+    same seeded program on its replica; rank 0 writes the files)."""
+    shard, shard_device = _join_process_group(num_gpus)
     set_seeds(seed)
-    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    logger.info(f"Using device: {device}")
+    device = shard_device if shard_device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    logger.info(f"Using device: {device}" + (f" (rank {shard.rank} of {shard.world}, rows sharded)" if shard else ""))
     vocab = load_vocab(vocab_path)
     logger.info(f"Loaded vocabulary with {len(vocab)} tokens")
     embeddings = initialize_embeddings(vocab, embedding_dim, curvature, device, init_device)
@@ -96,12 +134,12 @@ def train_tokenizer(
             merge_threshold=merge_threshold, lr=learning_rate, device=device, hnsw_m=hnsw_m,
             hnsw_ef_construction=hnsw_ef_construction, hnsw_ef_search=hnsw_ef_search, cache_size=cache_size,
             rebuild_frequency=rebuild_frequency, use_approximate_search=not no_faiss,
-            sign_convention=sign_convention)
+            sign_convention=sign_convention, shard=shard)
         logger.info("Using FastHyperbolicTokenizer with the exact GPU candidate search (no FAISS on this path)")
     else:
         tokenizer = HyperbolicTokenizer(vocab=vocab, embeddings=torch.nn.Parameter(embeddings), curvature=curvature,
                                         merge_threshold=merge_threshold, lr=learning_rate, device=device,
-                                        sign_convention=sign_convention)
+                                        sign_convention=sign_convention, shard=shard)
         logger.info("Using standard HyperbolicTokenizer")
     logger.info("Created hyperbolic tokenizer")
 
@@ -146,11 +184,17 @@ def train_tokenizer(
             if step > 0 and step % 1000 == 0:
                 tokenizer.merge_threshold *= 1.05
 
-    os.makedirs(output_dir, exist_ok=True)
-    tokenizer.save(output_dir)
-    logger.info(f"Saved tokenizer to {output_dir}")
-    with open(os.path.join(output_dir, "training_stats.json"), "w") as f:
-        json.dump(stats, f)
+    if shard is None or shard.rank == 0:          # identical replicas: one writer
+        os.makedirs(output_dir, exist_ok=True)
+        tokenizer.save(output_dir)
+        logger.info(f"Saved tokenizer to {output_dir}")
+        with open(os.path.join(output_dir, "training_stats.json"), "w") as f:
+            json.dump(stats, f)
+    if shard is not None:
+        import torch.distributed as dist
+        dist.barrier()
+        if getattr(shard, "owns_group", False):
+            dist.destroy_process_group()
     return stats
 
 
@@ -174,6 +218,7 @@ def main(
     no_faiss: bool = False,
     sign_convention: str = "reference",
     init_device: Optional[str] = None,
+    num_gpus: Optional[int] = None,
 ) -> None:
     """Train a hyperbolic tokenizer with the given parameters."""
     train_tokenizer(vocab_path=vocab_path, output_dir=output_dir, embedding_dim=embedding_dim, curvature=curvature,
@@ -182,7 +227,7 @@ def main(
                     use_fast_tokenizer=use_fast_tokenizer, hnsw_m=hnsw_m,
                     hnsw_ef_construction=hnsw_ef_construction, hnsw_ef_search=hnsw_ef_search, cache_size=cache_size,
                     rebuild_frequency=rebuild_frequency, no_faiss=no_faiss, sign_convention=sign_convention,
-                    init_device=init_device)
+                    init_device=init_device, num_gpus=num_gpus)
 
 
 if __name__ == "__main__":

@@ -114,9 +114,10 @@ def test_merge_sequences_match_reference(golden_dir, mode):
     check_sequences(golden_dir, mode, OracleEngine, "cpu")
 
 
-def check_cli(golden_dir, mode, tmp_path, engine_factory, init_device="cpu"):
+def check_cli(golden_dir, mode, tmp_path, engine_factory, init_device="cpu", writer=True):
     """End-to-end CLI run on a copy of the reference's 45-line initial vocabulary (42 tokens after
-    load_vocab drops blanks): vocab.json, merges.json, config.json identical, live rows close."""
+    load_vocab drops blanks): vocab.json, merges.json, config.json identical, live rows close.
+    ``writer=False``: a rank of a multi-process launch that does not write the files (rank 0 does)."""
     from hyptokenizer_amd.scripts import train_hyperbolic_tokenizer as T
     res = json.load(open(os.path.join(golden_dir, f"cli_{mode}.json")))
     arr = np.load(os.path.join(golden_dir, f"cli_{mode}.npz"))
@@ -142,6 +143,9 @@ def check_cli(golden_dir, mode, tmp_path, engine_factory, init_device="cpu"):
                               merge_steps=8, log_every=4, target_vocab_size=500, seed=42, use_fast_tokenizer=fast,
                               no_faiss=True, sign_convention=mode, init_device=init_device)
             key = "fast" if fast else "std"
+            if not writer:
+                assert not os.path.exists(os.path.join(out, "vocab.json"))
+                continue
             assert json.load(open(os.path.join(out, "vocab.json"))) == res[key]["vocab"]
             assert json.load(open(os.path.join(out, "merges.json"))) == res[key]["merges"]
             cfg = json.load(open(os.path.join(out, "config.json")))
