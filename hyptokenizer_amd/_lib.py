@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HYPMERGE_LIB") or os.path.join(_HERE, "libhypmerge.so")
 
 HM_OK = 0
-HM_E_ARG, HM_E_CAPACITY, HM_E_STATE, HM_E_NOMEM, HM_E_COMM = -1, -2, -3, -4, -5
+HM_E_ARG, HM_E_CAPACITY, HM_E_STATE, HM_E_NOMEM, HM_E_COMM, HM_E_NA = -1, -2, -3, -4, -5, -6
 COMM_ID_BYTES = 128
 SIGN_REFERENCE, SIGN_LORENTZ = 0, 1
 PREFILTER_AUTO, PREFILTER_F32, PREFILTER_BF16 = 0, 1, 2

@@ -124,7 +124,10 @@ struct HostCtl {                 // pinned host mirror of small device results
 struct LoopState {
     uint32_t stop;               // 0 running, 1 no candidate, 2 emission overflow
     uint32_t steps_done;
-    ArgminRec best;              // incremental loop: running nearest pair (as of the start of the last executed step)
+    // incremental loop: running nearest pair, double-buffered by step parity: the blocks of step k read best[k & 1]
+    // (written by the previous launch, or by the host for k = 0) and block 0 writes the folded value to best[(k + 1) & 1]
+    // -- no slot is read and written in one launch
+    ArgminRec best[2];
     uint32_t pad[2];
     // incremental loop: nearest partner of the row appended by step k, folded in by every block with one 64-bit
     // atomicMin: (bits(d) << 32) | i  (the partner is always paired with that new row); all ones = none

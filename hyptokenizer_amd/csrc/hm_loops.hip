@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * HM_INCR_WAVES) void hm_incr_step_kernel(const 
     if (tl < nt) hm_tile_load(a.img, a.RS, tl * HM_TILE_ROWS, a.new_row, tr, lane);
     LoopState* loop = a.loop;
     const uint32_t stop = loop->stop;
-    ArgminRec best = loop->best;
+    ArgminRec best = loop->best[a.step & 1];
     if (a.step > 0 && stop == 0u) {
         const unsigned long long rk = loop->rowkey[a.step - 1];        // complete: the previous launch has ended
         if (rk != ~0ull) {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * HM_INCR_WAVES) void hm_incr_step_kernel(const 
             if (lane == 0) {
                 a.len[a.new_row] = li + lj;
                 *a.rec_ring = best;                        // the pair this step merged
-                loop->best = best;                         // the running minimum as of this step's start
+                loop->best[(a.step + 1) & 1] = best;       // the running minimum as of this step's start (read by the next launch)
                 loop->steps_done += 1u;
             }
         }
@@ -254,21 +254,21 @@ extern "C" int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_de
     const int64_t n0 = e->n;
     LoopState st;
     memset(&st, 0, sizeof(st));
-    st.best.found = best_io[0]; st.best.dbits = best_io[1]; st.best.i = best_io[2]; st.best.j = best_io[3];
-    memcpy(&e->h->rec2[0], &st.best, sizeof(ArgminRec));
+    st.best[0].found = best_io[0]; st.best[0].dbits = best_io[1]; st.best[0].i = best_io[2]; st.best[0].j = best_io[3];
+    memcpy(&e->h->rec2[0], &st.best[0], sizeof(ArgminRec));
     HM_HIP(hipMemsetAsync(e->d_loop, 0, sizeof(LoopState), s));
     HM_HIP(hipMemsetAsync(e->d_loop->rowkey, 0xff, sizeof(unsigned long long) * HM_LOOP_MAX_STEPS, s));
-    HM_HIP(hipMemcpyAsync(&e->d_loop->best, &e->h->rec2[0], sizeof(ArgminRec), hipMemcpyHostToDevice, s));
+    HM_HIP(hipMemcpyAsync(&e->d_loop->best[0], &e->h->rec2[0], sizeof(ArgminRec), hipMemcpyHostToDevice, s));
     IncrArgs a;
     a.img = e->img; a.img16 = e->img16; a.RS = e->RS; a.d = e->d; a.KC = e->KC; a.sign_mode = e->sign_mode;
     a.c = c; a.sqrt_c = sqrtf(c); a.thr = thr; a.X = X_dev; a.ld = ld; a.len = e->d_len; a.loop = e->d_loop;
     a.rmax2_bits = e->d_rmax2;
     const size_t lds = sizeof(float) * (size_t)HM_INCR_WAVES * HM_TILE_ROWS * e->RS;
-    static bool attr_done = false;
-    if (!attr_done) {
-        HM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hm_incr_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const void* incr_fn = reinterpret_cast<const void*>(&hm_incr_step_kernel);
+    if (e->attr_done.find(incr_fn) == e->attr_done.end()) {                    // per engine (= per device), not process-wide
+        HM_HIP(hipFuncSetAttribute(incr_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)(sizeof(float) * (size_t)HM_INCR_WAVES * HM_TILE_ROWS * 4 * HM_TILE_MAXQ)));
-        attr_done = true;
+        e->attr_done.insert(incr_fn);
     }
     for (int64_t k = 0; k < steps; ++k) {
         a.new_row = n0 + k;
@@ -280,7 +280,8 @@ extern "C" int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_de
         HM_HIP(hipGetLastError());
     }
     HM_HIP(hipMemcpyAsync(e->h->loop_recs, e->d_loop_recs, sizeof(ArgminRec) * (size_t)steps, hipMemcpyDeviceToHost, s));
-    HM_HIP(hipMemcpyAsync(&e->h->rec, &e->d_loop->best, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
+    // (the slot the last launch WROTE: step steps - 1 wrote best[steps & 1]; a launch that stopped wrote nothing -- unused then)
+    HM_HIP(hipMemcpyAsync(&e->h->rec, &e->d_loop->best[steps & 1], sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
     HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_loop->rowkey + (steps - 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HM_HIP(hipStreamSynchronize(s));
     hm_unpack_recs(e->h->loop_recs, steps, rec_out, done);

@@ -428,11 +428,11 @@ extern "C" int hm_row_vs_all(hm_engine* e, int64_t row, int64_t n, float c, floa
     if (n == 0) return HM_OK;
     {
         const size_t lds = sizeof(float) * ((size_t)HM_MAX_D1 + 4 + (size_t)HM_ROWVS_WAVES * HM_TILE_ROWS * e->RS);
-        static bool attr_done = false;
-        if (!attr_done) {
-            HM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&hm_rowvsall_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        const void* fn = reinterpret_cast<const void*>(&hm_rowvsall_kernel);
+        if (e->attr_done.find(fn) == e->attr_done.end()) {                      // per engine (= per device), not process-wide
+            HM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(sizeof(float) * ((size_t)HM_MAX_D1 + 4 + (size_t)HM_ROWVS_WAVES * HM_TILE_ROWS * 4 * HM_TILE_MAXQ))));
-            attr_done = true;
+            e->attr_done.insert(fn);
         }
         const int64_t nt = (n + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
         hipLaunchKernelGGL(hm_rowvsall_kernel, dim3((unsigned)std::min<int64_t>((nt + HM_ROWVS_WAVES - 1) / HM_ROWVS_WAVES, HM_ROWVS_GRID_CAP)), dim3(64 * HM_ROWVS_WAVES), lds,

@@ -1016,7 +1016,7 @@ extern "C" int hm_topk_refresh_begin(hm_engine* e, float c, float thr, int64_t k
     if (!e) return hm_fail(nullptr, HM_E_ARG, "hm_topk_refresh_begin: engine is NULL");
     if (e->refresh_pending) return hm_fail(e, HM_E_STATE, "hm_topk_refresh_begin: a refresh is already pending");
     if (!(c > 0.0f) || k <= 0 || k > (int64_t)e->sorted_cap) return hm_fail(e, HM_E_ARG, "hm_topk_refresh_begin: bad arguments");
-    if (!hm_topk_incremental_ok(e, c, thr, k)) return HM_E_STATE;                  // (no message: "not applicable" is an ordinary answer)
+    if (!hm_topk_incremental_ok(e, c, thr, k)) return HM_E_NA;                     // (no message: "not applicable" is an ordinary answer)
     HM_HIP(hipSetDevice(e->device));
     e->armed = false;
     const int rc = hm_topk_incremental_enqueue(e, c, thr, k, (hipStream_t)stream);

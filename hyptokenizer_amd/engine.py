@@ -162,7 +162,7 @@ class MergeEngine:
         (``False``: not of that kind -- use ``topk``).  Nothing else may be asked of the engine until
         ``topk_refresh_end``."""
         st = self._L.hm_topk_refresh_begin(self._h, _f(c), float(thr), int(k), self._stream())
-        if st == -3:                               # HM_E_STATE without a message: the refresh is not of the incremental kind
+        if st == _lib.HM_E_NA:                     # the refresh is not of the incremental kind (HM_E_STATE stays an error)
             return False
         self._chk(st)
         self._refresh_k = int(k)
@@ -387,6 +387,30 @@ class MergeEngine:
             self._chk(self._L.hm_coherence_batch(self._h, _ptr(ti), _ptr(tj), _ptr(tw), _ptr(ts), ti.numel(), S.shape[1],
                                                  _f(c), _ptr(out), self._stream()))
         return out.cpu().numpy()
+
+    def coherence_distances_begin(self, I, J, W, S, c: float):
+        """The same launch without the wait: kernel and the copy of its result into pinned host memory are enqueued and a
+        handle comes back at once -- the caller draws the NEXT batch's samples on the host meanwhile (the enhanced
+        tokenizer's scoring: the host RNG is the long pole) and collects with ``coherence_distances_end``."""
+        ti, tj = self._idx(I), self._idx(J)
+        tw = torch.as_tensor(np.ascontiguousarray(W, dtype=np.float32), device=self.device)
+        S = np.ascontiguousarray(S, dtype=np.int32).reshape(ti.numel(), -1)
+        ts = torch.as_tensor(S, device=self.device)
+        out = torch.empty(S.shape, dtype=torch.float32, device=self.device)
+        host = torch.empty(S.shape, dtype=torch.float32).pin_memory()
+        ev = torch.cuda.Event()
+        if S.size:
+            self._chk(self._L.hm_coherence_batch(self._h, _ptr(ti), _ptr(tj), _ptr(tw), _ptr(ts), ti.numel(), S.shape[1],
+                                                 _f(c), _ptr(out), self._stream()))
+            host.copy_(out, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return (host, ev, (ti, tj, tw, ts, out))           # (the operands stay referenced until the kernel has run)
+
+    @staticmethod
+    def coherence_distances_end(handle) -> np.ndarray:
+        host, ev, _keep = handle
+        ev.synchronize()
+        return host.numpy()
 
     def project_table(self, table: torch.Tensor, n_rows: int, c: float) -> None:
         """``project_to_hyperboloid`` over rows [0, n_rows) of ``table`` in place + image refresh

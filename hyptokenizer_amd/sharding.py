@@ -215,3 +215,56 @@ def sharded_topk(engine, ctx: ShardContext, c: float, thr: float, k: int):
     r0, r1 = ctx.row_range(engine.n)
     d, i, j, cnt = engine.topk(c, thr, k, r0, r1)
     return ctx.global_topk(d, i, j, cnt, k)
+
+
+def _all_gather_ragged(ctx: ShardContext, arr: np.ndarray) -> List[np.ndarray]:
+    """all-gather of per-rank int32 / float32 arrays of different lengths (first axis): lengths first, then the arrays
+    padded to the longest.  Returns the ranks' arrays in rank order."""
+    a = np.ascontiguousarray(arr)
+    width = int(np.prod(a.shape[1:])) if a.ndim > 1 else 1
+    raw = a.reshape(-1).view(np.int32)
+    lens = torch.zeros(ctx.world, dtype=torch.int64, device=ctx.device)
+    dist.all_gather_into_tensor(lens, torch.tensor([raw.size], dtype=torch.int64, device=ctx.device), group=ctx.group)
+    lens = lens.cpu().tolist()
+    cap = max(max(lens), 1)
+    mine = torch.zeros(cap, dtype=torch.int32, device=ctx.device)
+    if raw.size:
+        mine[:raw.size] = torch.from_numpy(raw.copy()).to(ctx.device)
+    out = torch.empty(ctx.world * cap, dtype=torch.int32, device=ctx.device)
+    dist.all_gather_into_tensor(out, mine, group=ctx.group)
+    flat = out.cpu().numpy().reshape(ctx.world, cap)
+    parts = []
+    for r in range(ctx.world):
+        p = flat[r, :lens[r]].view(a.dtype)
+        parts.append(p.reshape((-1,) + a.shape[1:]) if width > 1 or a.ndim > 1 else p)
+    return parts
+
+
+def sharded_candidates(engine, ctx: ShardContext, c: float, thr: float):
+    """Every candidate of the table in row-major order -- (i, j, d, total) as ``engine.candidates`` -- listed by row
+    ranges on the ranks and concatenated in rank order (the ranges ascend, each rank's list is row-major)."""
+    r0, r1 = ctx.row_range(engine.n)
+    i, j, d, _t = engine.candidates(c, thr, r0, r1)
+    gi = _all_gather_ragged(ctx, i.astype(np.int32))
+    gj = _all_gather_ragged(ctx, j.astype(np.int32))
+    gd = _all_gather_ragged(ctx, d.astype(np.float32))
+    ii, jj, dd = np.concatenate(gi), np.concatenate(gj), np.concatenate(gd)
+    return ii, jj, dd, int(len(ii))
+
+
+COHERENCE_SHARD_MIN = 2048      # candidates per batch from which the coherence kernel's work is worth splitting over the ranks
+
+
+def sharded_coherence(engine, ctx: ShardContext, ii: np.ndarray, jj: np.ndarray, w: np.ndarray, samples: np.ndarray, c: float,
+                      min_count: Optional[int] = None) -> np.ndarray:
+    """``engine.coherence_distances`` with the candidates of a large batch (a refresh scores EVERY candidate) cut into
+    ``world`` contiguous slices, one per rank, and the distances all-gathered; small batches are computed by every rank
+    for itself (deterministic kernels: identical replicas, and an exchange costs more than the launch)."""
+    count = len(ii)
+    if count < (COHERENCE_SHARD_MIN if min_count is None else min_count) or ctx.world == 1:
+        return engine.coherence_distances(ii, jj, w, samples, c)
+    cuts = [count * r // ctx.world for r in range(ctx.world + 1)]
+    lo, hi = cuts[ctx.rank], cuts[ctx.rank + 1]
+    mine = engine.coherence_distances(ii[lo:hi], jj[lo:hi], w[lo:hi], samples[lo:hi], c) if hi > lo \
+        else np.zeros((0, samples.shape[1]), np.float32)
+    return np.concatenate(_all_gather_ragged(ctx, np.ascontiguousarray(mine, np.float32)), axis=0)

@@ -78,6 +78,37 @@ class EnhancedMergeCandidate(MergeCandidate):
         return self.combined_score < other.combined_score
 
 
+_RANDPERM_HELPER_OK = None
+
+
+def _randperm_helper_ok() -> bool:
+    """One-time check of the library's MT19937 helper against THIS torch build's ``torch.randperm`` -- prefix values and
+    the generator state left behind, at a small n and at n = 100 003 (the helper follows randperm's 32-bit draw and
+    Fisher-Yates order; a build that changes either would otherwise sample other coherence rows than the reference).
+    On a mismatch the helper is not used again: plain ``torch.randperm`` calls."""
+    global _RANDPERM_HELPER_OK
+    if _RANDPERM_HELPER_OK is None:
+        _RANDPERM_HELPER_OK = True                    # (so that the calls below go through the helper)
+        keep = torch.get_rng_state()
+        ok = True
+        try:
+            for n, ns, count in ((37, 5, 3), (100003, COHERENCE_SAMPLES, 2)):
+                torch.manual_seed(1234567 + n)
+                want = np.stack([torch.randperm(n)[:ns].numpy() for _ in range(count)]).astype(np.int32)
+                st_want = torch.get_rng_state()
+                torch.manual_seed(1234567 + n)
+                got = randperm_prefixes(n, ns, count)
+                ok = ok and np.array_equal(got, want) and torch.equal(torch.get_rng_state(), st_want)
+        except Exception:
+            ok = False
+        finally:
+            torch.set_rng_state(keep)
+        _RANDPERM_HELPER_OK = bool(ok)
+        if not ok:
+            logger.warning("hm_randperm_prefix disagrees with this torch build's randperm: using torch.randperm")
+    return _RANDPERM_HELPER_OK
+
+
 def randperm_prefixes(n: int, ns: int, count: int) -> np.ndarray:
     """``[torch.randperm(n)[:ns] for _ in range(count)]`` as an int32 ``[count, ns]`` array, consuming torch's
     CPU generator exactly as those calls do.  Served by the library's host helper ``hm_randperm_prefix`` (the
@@ -89,7 +120,7 @@ def randperm_prefixes(n: int, ns: int, count: int) -> np.ndarray:
             torch.randperm(n)
         return out
     st = torch.get_rng_state()
-    if st.numel() == 5056 and n < (2 ** 32 - 1) // 20 and ns <= 4096:
+    if st.numel() == 5056 and n < (2 ** 32 - 1) // 20 and ns <= 4096 and _randperm_helper_ok():
         from .. import _lib
         import ctypes as C
         raw = st.numpy().copy()
@@ -288,11 +319,27 @@ class EnhancedFastHyperbolicTokenizer(FastHyperbolicTokenizer):
         count = len(ii)
         if not self.use_frequency_aware or count == 0:
             return np.zeros(count, np.float64)
-        samples = self._coherence_samples(count)
         lens = self._token_lengths()                      # len(vocab[r]), kept as an array and extended as tokens are appended
         li, lj = lens[ii], lens[jj]
         w = (lj / (li + lj)).astype(np.float64)           # weight_j, a Python double in the reference (:316)
-        dist = self._get_engine().coherence_distances(ii, jj, w.astype(np.float32), samples, self._c())
+        eng = self._get_engine()
+        if self.shard is not None:
+            from ..sharding import sharded_coherence
+            samples = self._coherence_samples(count)          # (every rank draws the same samples: same seeded generator)
+            dist = sharded_coherence(eng, self.shard, ii, jj, w.astype(np.float32), samples, self._c())
+        elif count >= 64 and hasattr(eng, "coherence_distances_begin"):
+            # two halves, samples drawn in candidate order as ever: while the first half's kernel and result copy run, the
+            # host draws the second half's permutations (the long pole: one MT19937 pass over n draws per candidate)
+            h = count // 2
+            s0 = self._coherence_samples(h)
+            pend = eng.coherence_distances_begin(ii[:h], jj[:h], w[:h].astype(np.float32), s0, self._c())
+            s1 = self._coherence_samples(count - h)
+            d1 = eng.coherence_distances(ii[h:], jj[h:], w[h:].astype(np.float32), s1, self._c())
+            samples = np.concatenate([s0, s1])
+            dist = np.concatenate([eng.coherence_distances_end(pend), d1])
+        else:
+            samples = self._coherence_samples(count)
+            dist = eng.coherence_distances(ii, jj, w.astype(np.float32), samples, self._c())
         keep = (samples != ii[:, None]) & (samples != jj[:, None])
         avg = _row_means(dist, keep)
         with np.errstate(over="ignore", invalid="ignore"):
@@ -494,7 +541,11 @@ class EnhancedFastHyperbolicTokenizer(FastHyperbolicTokenizer):
             return basic
         if isinstance(basic, CandidateList):
             if len(basic) > basic.stored:
-                i, j, d, _total = self._get_engine().candidates(self._c(), self._search_threshold())
+                if self.shard is not None:
+                    from ..sharding import sharded_candidates
+                    i, j, d, _total = sharded_candidates(self._get_engine(), self.shard, self._c(), self._search_threshold())
+                else:
+                    i, j, d, _total = self._get_engine().candidates(self._c(), self._search_threshold())
                 order = np.argsort(d, kind="stable")          # row-major list, stable by distance = S
                 dd, ii, jj = d[order], i[order], j[order]
             else:

@@ -103,12 +103,24 @@ class AdaptiveMergeCache:
     # -- the reference's public attributes ------------------------------------------------------
     @property
     def hit_count(self) -> Dict[Tuple[int, int], int]:
-        """served pairs -> times served; batches popped as arrays are folded in when this is read"""
+        """served pairs -> times served; batches popped as arrays are folded in when this is read (or when more than
+        ``_SERVED_MAX`` of them have piled up: each entry pins a whole refresh's arrays)"""
+        self._fold_served()
+        return self._hit_count
+
+    _SERVED_MAX = 64
+
+    def _fold_served(self) -> None:
         for ii, jj, lo, hi in self._served:
             for key in zip(ii[lo:hi].tolist(), jj[lo:hi].tolist()):
                 self._hit_count[key] = self._hit_count.get(key, 0) + 1
         self._served = []
-        return self._hit_count
+
+    def _note_served(self, ii, jj, lo: int, hi: int) -> None:
+        self._served.append((ii, jj, lo, hi))
+        self._hits += hi - lo
+        if len(self._served) > self._SERVED_MAX:
+            self._fold_served()
 
     @hit_count.setter
     def hit_count(self, value) -> None:
@@ -175,8 +187,7 @@ class AdaptiveMergeCache:
             self._pos = hi
             if hi >= len(d):
                 self._arr, self._pos = None, 0
-            self._served.append((i, j, lo, hi))
-            self._hits += hi - lo
+            self._note_served(i, j, lo, hi)
             return CandidateList(d[lo:hi], i[lo:hi], j[lo:hi], hi - lo)
         best = self._list[:n]
         self._list = self._list[n:]
@@ -386,8 +397,7 @@ class FastHyperbolicTokenizer(HyperbolicTokenizer):
         self.token2idx.update(zip(merged, range(n, n + k)))
         self.merge_history.extend(zip(lefts, rights, merged))
         hi = min(pos + 100 * k, n_arr)
-        cache._served.append((i_arr, j_arr, pos, hi))
-        cache._hits += hi - pos
+        cache._note_served(i_arr, j_arr, pos, hi)
         if hi >= n_arr:
             cache._arr, cache._pos = None, 0
         else:

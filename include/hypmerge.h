@@ -41,6 +41,7 @@ extern "C" {
 #define HM_E_STATE      (-3)   /* call order violated (e.g. scan before hm_set_table)        */
 #define HM_E_NOMEM      (-4)
 #define HM_E_COMM       (-5)   /* RCCL could not be loaded / a collective failed            */
+#define HM_E_NA         (-6)   /* the request does not apply to the engine's current state: an ordinary answer, no message */
 
 #define HM_SIGN_REFERENCE 0
 #define HM_SIGN_LORENTZ   1
@@ -104,9 +105,9 @@ int hm_pairwise_topk(hm_engine* e, float c, float thr, int64_t k, int64_t row_be
 int hm_pairwise_topk_nocount(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end,
                              float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count, void* stream);
 /* The same refresh in two halves for callers that have host work to do meanwhile (the fast tokenizer's string
- * bookkeeping): hm_topk_refresh_begin enqueues the whole chain and returns at once -- HM_E_STATE (without a message) when
+ * bookkeeping): hm_topk_refresh_begin enqueues the whole chain and returns at once -- HM_E_NA when
  * the refresh is not of the incremental kind (rows changed, other k / curvature, lower threshold: use
- * hm_pairwise_topk_nocount) --, hm_topk_refresh_end waits and delivers the ordered list (HM_E_CAPACITY: more new entries
+ * hm_pairwise_topk_nocount; HM_E_STATE stays a real error: a refresh already pending) --, hm_topk_refresh_end waits and delivers the ordered list (HM_E_CAPACITY: more new entries
  * than the device-side sort takes; the state is untouched, run hm_pairwise_topk_nocount).  No other call on the engine in
  * between. */
 int hm_topk_refresh_begin(hm_engine* e, float c, float thr, int64_t k, void* stream);

@@ -178,3 +178,66 @@ def test_cli_num_gpus_must_match_the_launch(monkeypatch):
     with pytest.raises(SystemExit):
         T._join_process_group(4)
     assert T._join_process_group(1) == (None, None) and T._join_process_group(None) == (None, None)
+
+
+def _enhanced_run(golden_dir, shard, min_count=None):
+    """a G5-style run of config 5 (frequency-aware + adaptive curvature) on the oracle-backed engine: scores of the first
+    refresh, merge history, threshold, merged rows"""
+    import hyptokenizer_amd.sharding as S
+    from test_enhanced_golden import load_g5, make_tok, oracle_engine, seed_all
+    if min_count is not None:
+        S.COHERENCE_SHARD_MIN = min_count
+    z, meta = load_g5(golden_dir, "lorentz")
+    seed_all(123)
+    tok = make_tok(z, meta, "lorentz", "freq_only", oracle_engine, use_adaptive_curvature=True, optimize_curvature_freq=7,
+                   cache_size=40, shard=shard)       # (a cache smaller than the candidate count: the refresh lists ALL candidates)
+    n0 = tok.current_vocab_size
+    scored = tok._find_merge_candidates_fast()
+    first = [(c.token_i, c.token_j, float(c.combined_score), float(c.semantic_score)) for c in scored[:200]]
+    seed_all(123)
+    tok2 = make_tok(z, meta, "lorentz", "freq_only", oracle_engine, use_adaptive_curvature=True, optimize_curvature_freq=7,
+                    cache_size=40, shard=shard)
+    tok2.optimize_merges(steps=24, log_every=10 ** 9, adaptive_threshold=False)
+    return {"first": first, "n_scored": len(scored), "merges": list(tok2.merge_history), "thr": tok2.merge_threshold,
+            "curv": repr(float(torch.as_tensor(tok2.get_curvature()).detach())),        # (repr: a NaN equals a NaN)
+            "rows": tok2.embeddings.data[n0:tok2.current_vocab_size].numpy().view(np.uint32).tolist()}
+
+
+def _enhanced_worker(rank, world, port, golden_dir, q):
+    os.environ["TQDM_DISABLE"] = "1"
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hyptokenizer_amd.sharding import ShardContext
+        torch.set_num_threads(1)
+        q.put((rank, _enhanced_run(golden_dir, ShardContext(), min_count=8)))    # (8: the coherence batches ARE partitioned)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_enhanced_tokenizer_row_sharded_equals_single_process(golden_dir):
+    """BASELINE config 5 on more than one rank: EnhancedFastHyperbolicTokenizer(shard=ctx) -- sharded candidate search and
+    listing, coherence batches partitioned by candidate over the ranks and all-gathered, the same seeded generator on every
+    rank -- reproduces the single-process run: candidate order and scores of a refresh, merges, curvature, merged rows."""
+    os.environ["TQDM_DISABLE"] = "1"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    ref = _enhanced_run(golden_dir, None)
+    assert ref["n_scored"] > 40 and len(ref["merges"]) >= 10
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_enhanced_worker, args=(r, world, port, golden_dir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert results[r] == ref, r
