@@ -58,7 +58,12 @@ int         hm_abi_version(void);
 const char* hm_last_error(const hm_engine* e);          /* e may be NULL: last global error */
 
 /* One engine per device.  Allocates the scan image ([max_rows] rows) and all workspaces; nothing
- * is allocated in the per-call path afterwards.  d1 = d + 1 (2 <= d1 <= 129).
+ * is allocated in the per-call path afterwards.
+ * LIMITS (narrower than the reference, which takes any max_vocab_size; both are rejected here with HM_E_ARG, by the Python
+ * classes at construction with a ValueError):
+ *   2 <= max_rows <= 131072   -- a row index has 17 bits in the 32-bit (i, j) word of the pair scan's 64-bit running key;
+ *   2 <= d1 = d + 1 <= 129    -- kernels are instantiated for d <= 128; the bf16 prefilter exists for d <= 124 (d + 4 K-slots
+ *                                in at most 16 chunks of 8), wider tables use the fp32 prefilter.
  * Replaces: the pre-allocated table of HyperbolicTokenizer.__init__ (hyperbolic_merge.py:144-153)
  * as far as the search kernels are concerned, and the FAISS index objects
  * (_init_faiss_index :593-605, _build_faiss_index fast...:195-240), which are not used at all. */
