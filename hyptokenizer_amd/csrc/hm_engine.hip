@@ -40,7 +40,8 @@ extern "C" int hm_abi_version(void) { return HM_ABI_VERSION; }
 
 // ---- work-decomposition knobs (test / tuning hook: hm_debug_set_knob, hm_debug_set_default_knob) ----
 #if defined(HM_TUNING)
-static const char* const kKnobNames[] = {"chunk", "tail", "tail_div", "big_rows", "shape", "incr_topk", "kc_even"};
+static const char* const kKnobNames[] = {"chunk", "tail", "tail_div", "big_rows", "shape", "incr_topk", "kc_even", "phases", "ph_share0", "ph_share1", "ph_share2",
+                                        "ph_div1", "ph_div2", "ph_div3"};
 #endif
 static std::map<std::string, double> g_default_knobs;          // applied to every engine created afterwards
 
@@ -53,6 +54,9 @@ static int hm_apply_knob(hm_engine* e, const char* name, double v)
     else if (k == "big_rows") { if (!(v >= 0)) return HM_E_ARG; e->big_min_rows = (int64_t)v; }          // 512-row blocks from this many rows' pairs on
     else if (k == "shape") { if (!(v >= -1 && v <= 4)) return HM_E_ARG; e->force_shape = (int)v; }
     else if (k == "incr_topk") e->incremental_topk = v != 0.0;
+    else if (k == "phases") { if (!(v >= 1 && v <= HM_SCAN_PHASES)) return HM_E_ARG; e->phases = (int)v; }
+    else if (k == "ph_share0" || k == "ph_share1" || k == "ph_share2") { if (!(v >= 0.0 && v <= 1.0)) return HM_E_ARG; e->ph_share[k[8] - '0'] = v; }
+    else if (k == "ph_div1" || k == "ph_div2" || k == "ph_div3") { if (!(v >= 1 && v <= 64)) return HM_E_ARG; e->ph_div[k[6] - '0'] = (int)v; }
     else if (k == "kc_even") {            // bf16 image with an even chunk count (whole k-steps only): default knob only, before the images exist
         if (e->img16 != nullptr) return HM_E_STATE;
         if (v != 0.0 && (e->KC & 1)) { e->KC += 1; e->RB16 = 16 * hm_row16_chunks(e->KC); }

@@ -481,15 +481,12 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     };
 
     // ---- work distribution: static, block b owns item b of the host's list (hm_prepare_scan) ----
-    if ((int)blockIdx.x < p.n_items_a) {
-        rb = p.rb_first + (int)blockIdx.x / p.chunks_a;
-        ct0 = p.ctmin_a + ((int)blockIdx.x % p.chunks_a) * p.ch_a;
-        ct1 = ct0 + p.ch_a;
-    } else {
-        const int it = (int)blockIdx.x - p.n_items_a;
-        rb = p.rb_split + it / p.chunks_b;
-        ct0 = p.ctmin_b + (it % p.chunks_b) * p.ch_b;
-        ct1 = ct0 + p.ch_b;
+    {
+        int it = (int)blockIdx.x, ph = 0;
+        while (ph + 1 < p.n_ph && it >= p.ph_items[ph]) { it -= p.ph_items[ph]; ++ph; }
+        rb = p.ph_rb0[ph] + it / p.ph_chunks[ph];
+        ct0 = p.ph_ctmin[ph] + (it % p.ph_chunks[ph]) * p.ph_ch[ph];
+        ct1 = ct0 + p.ph_ch[ph];
     }
     if (ct0 < (rb * BLOCK_ROWS) / COLS) ct0 = (rb * BLOCK_ROWS) / COLS;   // left of the diagonal: no i < j
     if (ct0 < p.col_begin / COLS) ct0 = p.col_begin / COLS;               // partner rows in front of col_begin are not asked for
@@ -807,30 +804,45 @@ bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t r
     int ch = (a.bf16 ? e->chunk_bf16 : e->chunk_f32) * 64 / cols;
     if (ch < 1) ch = 1;
     while (ch > 4 && (int64_t)nrb * ((a.nct + ch - 1) / ch) < 1024) ch >>= 1;
-    // phase B = the last ~tail_fraction of the work (row blocks near the bottom of the triangle), cut into
-    // chunks a quarter the size
+    // phases: cut the launch's row blocks (top down: longest rows first) at the cumulative work shares; chunk lengths
+    // ch, ch / div[1], ch / div[2], ... (a small launch keeps one phase)
     a.col_begin = (int)std::max<int64_t>(col_begin, 0);
     const int ct_lo = a.col_begin / cols;
-    a.ctmin_a = std::max((int)((int64_t)a.rb_first * block_rows / cols), ct_lo);
-    int rb_split = rb_last + 1;
-    int ch_b = ch;
+    int nph = 1;
+    double share[HM_SCAN_PHASES] = {1.0, 0.0, 0.0, 0.0};
+    int div[HM_SCAN_PHASES] = {1, 1, 1, 1};
     if (ch >= 8 && nrb >= 16) {
-        double total = 0.0, acc = 0.0;
-        for (int rb = a.rb_first; rb <= rb_last; ++rb) total += (double)std::max(0, a.nct - rb * tiles_per_rb);
-        for (int rb = rb_last; rb >= a.rb_first; --rb) {
-            acc += (double)std::max(0, a.nct - rb * tiles_per_rb);
-            if (acc >= e->tail_fraction * total) { rb_split = rb; break; }
+        if (e->phases <= 2) {
+            nph = 2;
+            share[0] = 1.0 - e->tail_fraction; share[1] = e->tail_fraction;
+            div[1] = e->tail_div;
+        } else {
+            nph = std::min(e->phases, HM_SCAN_PHASES);
+            double rest = 1.0;
+            for (int q = 0; q < nph - 1; ++q) { share[q] = e->ph_share[q]; rest -= share[q]; }
+            share[nph - 1] = std::max(rest, 0.0);
+            for (int q = 0; q < nph; ++q) div[q] = e->ph_div[q];
         }
-        ch_b = std::max(1, ch / e->tail_div);
     }
-    a.ch_a = ch;
-    a.chunks_a = std::max(1, (a.nct - a.ctmin_a + ch - 1) / ch);
-    a.rb_split = rb_split;
-    a.ch_b = ch_b;
-    a.ctmin_b = std::max((int)((int64_t)rb_split * block_rows / cols), ct_lo);
-    a.chunks_b = std::max(1, (a.nct - a.ctmin_b + ch_b - 1) / ch_b);
-    a.n_items_a = (rb_split - a.rb_first) * a.chunks_a;
-    const int n_items_b = (rb_last + 1 - rb_split) * a.chunks_b;
-    grid = dim3((unsigned)std::max(1, a.n_items_a + n_items_b), 1, 1);
+    double total = 0.0;
+    for (int rb = a.rb_first; rb <= rb_last; ++rb) total += (double)std::max(0, a.nct - rb * tiles_per_rb);
+    a.n_ph = nph;
+    int rb_at = a.rb_first, n_items = 0;
+    double acc = 0.0, want = 0.0;
+    for (int q = 0; q < nph; ++q) {
+        want += share[q] * total;
+        int rb_end = rb_at;
+        if (q == nph - 1) rb_end = rb_last + 1;
+        else while (rb_end <= rb_last && acc < want) { acc += (double)std::max(0, a.nct - rb_end * tiles_per_rb); ++rb_end; }
+        const int chq = std::max(1, ch / std::max(1, div[q]));
+        a.ph_rb0[q] = rb_at;
+        a.ph_ch[q] = chq;
+        a.ph_ctmin[q] = std::max((int)((int64_t)rb_at * block_rows / cols), ct_lo);
+        a.ph_chunks[q] = std::max(1, (a.nct - a.ph_ctmin[q] + chq - 1) / chq);
+        a.ph_items[q] = (rb_end - rb_at) * a.ph_chunks[q];
+        n_items += a.ph_items[q];
+        rb_at = rb_end;
+    }
+    grid = dim3((unsigned)std::max(1, n_items), 1, 1);
     return true;
 }
