@@ -104,6 +104,13 @@ struct ScanArgs {
     int sample_stride;
     const uint32_t* rmax2_bits;   // [0] largest squared row norm, [1] largest squared spatial norm (float bits)
     const uint32_t* stop;         // device-resident loops: a non-zero word makes every block return at once (may be NULL)
+    // pipelined loop: this scan reads what the tail kernel of two steps ago wrote (a row, the armed counters).  That kernel ran
+    // on another stream a whole scan ago; instead of a stream-level event wait (6 us on this stream per step) every block
+    // checks that `*order_seen >= order_need` and, should it ever not hold, raises the loop's stop word to 5 and leaves -- the
+    // host then redoes the remaining steps strictly sequentially.  A guard, never a wait.
+    const uint32_t* order_seen;
+    uint32_t order_need;
+    uint32_t* order_fault;
 };
 
 // Seed of the argmin search's running key, kept on the device between searches: the key of the last
@@ -125,13 +132,14 @@ struct HostCtl {                 // pinned host mirror of small device results
 
 // state of the device-resident merge loops (one per engine, in HBM)
 struct LoopState {
-    uint32_t stop;               // 0 running, 1 no candidate, 2 emission overflow
+    uint32_t stop;               // 0 running, 1 no candidate, 2 emission overflow, 5 pipelined loop: a scan started before its inputs were written
     uint32_t steps_done;
     // incremental loop: running nearest pair, double-buffered by step parity: the blocks of step k read best[k & 1]
     // (written by the previous launch, or by the host for k = 0) and block 0 writes the folded value to best[(k + 1) & 1]
     // -- no slot is read and written in one launch
     ArgminRec best[2];
-    uint32_t pad[2];
+    uint32_t tails_done;         // pipelined loop: tail kernels that have finished (the scans' order guard)
+    uint32_t pad[1];
     // incremental loop: nearest partner of the row appended by step k, folded in by every block with one 64-bit
     // atomicMin: (bits(d) << 32) | i  (the partner is always paired with that new row); all ones = none
     unsigned long long rowkey[HM_LOOP_MAX_STEPS];
@@ -180,6 +188,14 @@ struct hm_engine {
     uint4* h_sorted = nullptr;             // pinned
     uint32_t sorted_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // software-pipelined standard loop: a second (high-priority) stream for the step's tail work, which then runs under
+    // the NEXT step's scan; per buffer set an event behind the scan and one behind the tail; the new row's key per set
+    bool pipeline = true;
+    int64_t pipeline_min_pairs = 400000000ll;   // (knob "pipeline_pairs")
+    int pipe_fault_at = -1;              // test hook (knob "pipe_fault_at"): the scan of this step of the next batch is made to trip its order guard
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_scan[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr}, ev_join = nullptr;
+    unsigned long long* d_rowkey = nullptr;     // 2 keys
     // cut prediction for top-k: valid while rows are only appended
     bool have_cut = false;
     uint32_t last_cut_bits = 0;
@@ -279,6 +295,13 @@ struct MergeFuse {
     int32_t* len_rw;
     LoopState* loop;        // stop flag / step counter (may be nullptr)
     ArgminRec* rec_ring;    // record of this step is also written here (may be nullptr)
+    // software-pipelined loop (hm_loops.hip): this step's scan left its entries / counters in the buffer set given here
+    // (nullptr: the engine's first set), and the newest row's nearest partner -- which that scan did not cover -- waits in
+    // *rowkey as (bits(d) << 32) | i, all ones = none; the tail folds it in, re-arms the set and clears the key
+    uint4* pipe_ent;
+    unsigned long long* pipe_ctr64;
+    unsigned long long* rowkey;
+    uint32_t rowkey_j;
 };
 int hm_launch_seed_init(hm_engine* e, const ScanArgs& a, hipStream_t s);
 int hm_launch_argmin_tail(hm_engine* e, const ScanArgs& a, float sqrt_c, float thr, ArgminRec* rec_out, bool with_seed,

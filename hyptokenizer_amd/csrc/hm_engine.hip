@@ -41,7 +41,7 @@ extern "C" int hm_abi_version(void) { return HM_ABI_VERSION; }
 // ---- work-decomposition knobs (test / tuning hook: hm_debug_set_knob, hm_debug_set_default_knob) ----
 #if defined(HM_TUNING)
 static const char* const kKnobNames[] = {"chunk", "tail", "tail_div", "big_rows", "shape", "incr_topk", "kc_even", "phases", "ph_share0", "ph_share1", "ph_share2",
-                                        "ph_div1", "ph_div2", "ph_div3"};
+                                        "ph_div1", "ph_div2", "ph_div3", "pipeline", "pipe_fault_at", "pipeline_pairs"};
 #endif
 static std::map<std::string, double> g_default_knobs;          // applied to every engine created afterwards
 
@@ -57,6 +57,9 @@ static int hm_apply_knob(hm_engine* e, const char* name, double v)
     else if (k == "phases") { if (!(v >= 1 && v <= HM_SCAN_PHASES)) return HM_E_ARG; e->phases = (int)v; }
     else if (k == "ph_share0" || k == "ph_share1" || k == "ph_share2") { if (!(v >= 0.0 && v <= 1.0)) return HM_E_ARG; e->ph_share[k[8] - '0'] = v; }
     else if (k == "ph_div1" || k == "ph_div2" || k == "ph_div3") { if (!(v >= 1 && v <= 64)) return HM_E_ARG; e->ph_div[k[6] - '0'] = (int)v; }
+    else if (k == "pipeline") e->pipeline = v != 0.0;       // standard loop: the step's tail work under the next step's scan (0: strictly sequential)
+    else if (k == "pipe_fault_at") e->pipe_fault_at = (int)v;
+    else if (k == "pipeline_pairs") { if (!(v >= 0)) return HM_E_ARG; e->pipeline_min_pairs = (int64_t)v; }
     else if (k == "kc_even") {            // bf16 image with an even chunk count (whole k-steps only): default knob only, before the images exist
         if (e->img16 != nullptr) return HM_E_STATE;
         if (v != 0.0 && (e->KC & 1)) { e->KC += 1; e->RB16 = 16 * hm_row16_chunks(e->KC); }
@@ -113,8 +116,10 @@ static int hm_engine_alloc(hm_engine* e)
     HM_HIP(hipMemset(e->d_ctr, 0, sizeof(uint32_t) * 8));
     HM_HIP(hipMalloc(&e->d_rmax2, sizeof(uint32_t) * 2));
     HM_HIP(hipMemset(e->d_rmax2, 0, sizeof(uint32_t) * 2));
-    HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 4));
-    HM_HIP(hipMemset(e->d_ctr64, 0, sizeof(unsigned long long) * 4));
+    HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 8));            // two sets of 4 (the second: pipelined loop)
+    HM_HIP(hipMemset(e->d_ctr64, 0, sizeof(unsigned long long) * 8));
+    HM_HIP(hipMalloc(&e->d_rowkey, sizeof(unsigned long long) * 2));
+    HM_HIP(hipMemset(e->d_rowkey, 0xff, sizeof(unsigned long long) * 2));
     HM_HIP(hipMalloc(&e->d_seed, sizeof(ArgminSeed)));
     HM_HIP(hipMemset(e->d_seed, 0, sizeof(ArgminSeed)));
     HM_HIP(hipMalloc(&e->d_rec, 2 * sizeof(ArgminRec)));
@@ -202,13 +207,19 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     (void)hipSetDevice(e->device);
     (void)hm_comm_destroy(e);
     void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts,
-                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch};
+                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch, e->d_rowkey};
     for (void* q : dev_ptrs)
         if (q) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);
     if (e->h_sorted) (void)hipHostFree(e->h_sorted);
     if (e->h_batch) (void)hipHostFree(e->h_batch);
     if (e->ev_batch) (void)hipEventDestroy(e->ev_batch);
+    for (int q = 0; q < 2; ++q) {
+        if (e->ev_scan[q]) (void)hipEventDestroy(e->ev_scan[q]);
+        if (e->ev_tail[q]) (void)hipEventDestroy(e->ev_tail[q]);
+    }
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     for (hipEvent_t ev : e->loop_evs) (void)hipEventDestroy(ev);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);

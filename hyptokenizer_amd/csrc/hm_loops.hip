@@ -59,6 +59,149 @@ static void hm_unpack_recs(const ArgminRec* recs, int64_t steps, uint32_t* rec_o
     *done = ok;
 }
 
+// ------------------------------------------------------------------------------------------------
+// software-pipelined standard loop
+// ------------------------------------------------------------------------------------------------
+// A step's tail work -- exact re-evaluation, record, merge (one wave of latency-bound transcendental arithmetic: 12-15 us
+// with its launch boundaries) -- used to sit between two scans.  Only the pairs of the NEWEST row depend on it.  So step k
+// is split: scan_old(k) covers the pairs among the rows that existed two merges ago (all but the newest row) and follows
+// scan_old(k - 1) back to back on the caller's stream; the newest row's nearest partner is found by a small row pass and
+// folded in by tail(k), both on the engine's second stream -- under scan_old(k + 1).  Dependencies (events):
+//   scan_old(k) after tail(k - 2);  rowpass(k) after tail(k - 1) (stream order);  tail(k) after scan_old(k) and rowpass(k).
+// Two buffer sets (emission entries, counters, row key) alternate between the steps; tail(k) re-arms its set for step
+// k + 2 with the seed of step k (the pair it merged from still exists: a valid bound).  Every pair is still evaluated in
+// every step; results are bit-identical to the sequential chain (tests run both).
+
+// nearest partner of image row `row` among rows [0, row): (bits(d) << 32) | i folded into *key by atomicMin (d < thr)
+__global__ __launch_bounds__(64) void hm_newrow_key_kernel(const float* __restrict__ img, int RS, int d, int64_t row, float sqrt_c, float thr,
+                                                           int sign_mode, unsigned long long* __restrict__ key, const uint32_t* __restrict__ stop)
+{
+    extern __shared__ __align__(16) float lds[];
+    if (stop != nullptr && *stop != 0u) return;
+    float* xs = lds;
+    const int lane = threadIdx.x;
+    float* tile = lds + HM_MAX_D1 + 4;
+    const int64_t nt = (row + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
+    int64_t tl = blockIdx.x;
+    TileRegs tr;
+    if (tl < nt) hm_tile_load(img, RS, tl * HM_TILE_ROWS, row, tr, lane);
+    for (int k = lane; k < RS; k += 64) xs[k] = img[row * RS + k];
+    hm_wave_lds_sync();
+    unsigned long long best = ~0ull;
+    for (; tl < nt; tl += gridDim.x) {
+        hm_tile_store(tile, RS, tr, lane);
+        hm_wave_lds_sync();
+        const int64_t nxt = tl + gridDim.x;
+        if (nxt < nt) hm_tile_load(img, RS, nxt * HM_TILE_ROWS, row, tr, lane);
+        const float u = hm_tile_u(tile, RS, d, xs, sign_mode, lane);
+        const int64_t i = tl * HM_TILE_ROWS + lane;
+        const float dd = hm::dist_from_u(u, sqrt_c);
+        if (i < row && dd < thr) {
+            const unsigned long long k64 = ((unsigned long long)hm::fbits(dd) << 32) | (unsigned long long)(uint32_t)i;
+            best = k64 < best ? k64 : best;
+        }
+        hm_wave_lds_sync();
+    }
+    best = hm_wave_min_u64(best);
+    if (lane == 0 && best != ~0ull) atomicMin(key, best);
+}
+
+static int hm_pipeline_init(hm_engine* e)
+{
+    if (e->aux) return HM_OK;
+    int lo = 0, hi = 0;
+    HM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));              // (hi = the numerically lowest = highest priority)
+    HM_HIP(hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, hi));
+    for (int q = 0; q < 2; ++q) {
+        HM_HIP(hipEventCreateWithFlags(&e->ev_scan[q], hipEventDisableSystemFence));      // (recorded by the scan's dispatch, like the timing events)
+        HM_HIP(hipEventCreateWithFlags(&e->ev_tail[q], hipEventDisableTiming));
+    }
+    HM_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    return HM_OK;
+}
+
+static int hm_std_merge_steps_pipelined(hm_engine* e, float c, float thr, const Bounds& b, float* X_dev, int64_t ld, int64_t steps, hipStream_t s,
+                                        int64_t* all_pairs, bool time_all, int64_t* timed_pairs)
+{
+    int rc = hm_pipeline_init(e);
+    if (rc) return rc;
+    const int64_t n0 = e->n;
+    const float sqrt_c = sqrtf(c);
+    hipStream_t sb = e->aux;
+    // the tail stream starts behind everything the caller's stream holds so far (table, token lengths, loop state)
+    HM_HIP(hipMemsetAsync(e->d_rowkey, 0xff, sizeof(unsigned long long) * 2, s));
+    HM_HIP(hipEventRecord(e->ev_join, s));
+    HM_HIP(hipStreamWaitEvent(sb, e->ev_join, 0));
+    const void* kfn = reinterpret_cast<const void*>(&hm_newrow_key_kernel);
+    const size_t row_lds = sizeof(float) * ((size_t)HM_MAX_D1 + 4 + (size_t)HM_TILE_ROWS * e->RS);
+    if (e->attr_done.find(kfn) == e->attr_done.end()) {
+        HM_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(float) * ((size_t)HM_MAX_D1 + 4 + (size_t)HM_TILE_ROWS * 4 * HM_TILE_MAXQ))));
+        e->attr_done.insert(kfn);
+    }
+    for (int64_t k = 0; k < steps; ++k) {
+        const int set = (int)(k & 1);
+        e->n = n0 + k;                                   // rows of step k's table (optimistic: corrected by the caller when the batch stops early)
+        const int64_t n_old = k == 0 ? e->n : e->n - 1;  // scan_old(k): all rows but the newest (step 0: the whole table)
+        ScanArgs a; dim3 grid;
+        if (!hm_prepare_scan(e, b, 0, -1, a, grid, n_old)) return hm_fail(e, HM_E_STATE, "hm_std_merge_steps: empty scan");
+        a.stop = &e->d_loop->stop;
+        a.ent = set ? e->ent2 : e->ent;
+        a.ctr64 = e->d_ctr64 + 4 * set;
+        // ---- caller's stream: scan_old(k) ----
+        if (k == 0) {
+            // both sets armed from the engine's seed before any tail runs (later steps: their set is armed by tail(k - 2))
+            ScanArgs a1 = a;
+            a1.ctr64 = e->d_ctr64 + 4;
+            rc = hm_launch_seed_init(e, a, s);
+            if (rc == HM_OK) rc = hm_launch_seed_init(e, a1, s);
+            if (rc) return rc;
+        } else if (k >= 2) {
+            // tail(k - 2) wrote this scan's newest row and armed its counters a whole scan ago, on the other stream: checked
+            // by the scan's blocks themselves (ScanArgs::order_*), not waited for with an event on this stream
+            a.order_seen = &e->d_loop->tails_done;
+            a.order_need = (uint32_t)(k - 1) + (e->pipe_fault_at == (int)k ? 1000000u : 0u);
+            a.order_fault = &e->d_loop->stop;
+        }
+        // The scan's completion event rides IN its dispatch (the kernel's own completion signal: no extra packet on this
+        // stream, where an hipEventRecord costs a 6 us bubble): the tail stream waits for that event.
+        const bool timed = (k == steps - 1);
+        hipEvent_t ev_start = nullptr, ev_stop = e->ev_scan[set];
+        if (time_all) {
+            if (k == 0) HM_HIP(hipEventRecord(e->loop_evs[2 * HM_LOOP_MAX_STEPS], s));
+            ev_start = e->loop_evs[2 * k]; ev_stop = e->loop_evs[2 * k + 1];
+            all_pairs[k] = hm_pairs_in_range(e->n, 0, e->n - 1);
+        } else if (timed) {
+            ev_start = e->ev0; ev_stop = e->ev1;
+        }
+        HM_HIP(hm_launch_scan(e, HM_MODE_ARGMIN, a, grid, s, ev_start, ev_stop));
+        if (timed) *timed_pairs = hm_pairs_in_range(e->n, 0, e->n - 1);
+        // ---- tail stream: rowpass(k) (behind tail(k - 1)), then tail(k) behind scan_old(k) ----
+        if (k >= 1) {
+            const int64_t row = e->n - 1;
+            const int64_t nt = (row + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
+            hipLaunchKernelGGL(hm_newrow_key_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(nt, 256))), dim3(64), row_lds, sb, e->img, e->RS,
+                               e->d, row, sqrt_c, thr, e->sign_mode, e->d_rowkey + set, &e->d_loop->stop);
+            HM_HIP(hipGetLastError());
+        }
+        HM_HIP(hipStreamWaitEvent(sb, ev_stop, 0));
+        MergeFuse mf;
+        memset(&mf, 0, sizeof(mf));
+        mf.X = X_dev; mf.ld = ld; mf.new_row = e->n; mf.c = c;
+        mf.len = e->d_len; mf.len_rw = e->d_len; mf.loop = e->d_loop; mf.rec_ring = e->d_loop_recs + k;
+        mf.pipe_ent = a.ent; mf.pipe_ctr64 = a.ctr64;
+        mf.rowkey = e->d_rowkey + set; mf.rowkey_j = (uint32_t)(e->n - 1);
+        rc = hm_launch_argmin_tail(e, a, sqrt_c, thr, e->d_rec, true, 0, 0x7fffffff, true, mf, sb);
+        if (rc) return rc;
+        HM_HIP(hipEventRecord(e->ev_tail[set], sb));
+    }
+    e->n = n0 + steps;
+    // the caller's stream continues behind the last tails
+    HM_HIP(hipStreamWaitEvent(s, e->ev_tail[(steps - 1) & 1], 0));
+    if (steps >= 2) HM_HIP(hipStreamWaitEvent(s, e->ev_tail[(steps - 2) & 1], 0));
+    return HM_OK;
+}
+
 // K steps of the standard loop.  rec_out: steps x {found, bits(d), i, j}; *done = leading steps that merged.
 // A record with found = 0 ends the loop (no candidate), found = 2 asks the caller to run that step through
 // hm_pairwise_argmin + hm_merge_append (emission overflow), found = 3 marks steps skipped after either.
@@ -89,7 +232,14 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
     const bool time_all = e->time_loops && !e->loop_evs.empty();
     if (time_all) hm_read_loop_events(e);         // the events are about to be reused
     int64_t all_pairs[HM_LOOP_MAX_STEPS];
-    for (int64_t k = 0; k < steps; ++k) {
+    // pipelined when a scan is long against a tail kernel (the tail of step k - 2 has to be through while scan k - 1 runs; the
+    // scans' order guard catches the rest): from ~28 000 rows of d = 100 on
+    const bool piped = e->pipeline && steps >= 2 && hm_pairs_in_range(e->n, 0, e->n - 1) >= e->pipeline_min_pairs;
+    if (piped) {
+        const int rcp = hm_std_merge_steps_pipelined(e, c, thr, b, X_dev, ld, steps, s, all_pairs, time_all, &timed_pairs);
+        if (rcp) { (void)hipStreamSynchronize(s); if (e->aux) (void)hipStreamSynchronize(e->aux); e->n = n0; return rcp; }
+    }
+    for (int64_t k = 0; k < (piped ? 0 : steps); ++k) {
         ScanArgs a; dim3 grid;
         if (!hm_prepare_scan(e, b, 0, -1, a, grid)) return hm_fail(e, HM_E_STATE, "hm_std_merge_steps: empty scan");
         a.stop = &e->d_loop->stop;
@@ -109,6 +259,7 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
         }
         if (timed) timed_pairs = hm_pairs_in_range(e->n, a.row_begin, a.row_end);
         MergeFuse mf;
+        memset(&mf, 0, sizeof(mf));
         mf.X = X_dev; mf.ld = ld; mf.new_row = e->n; mf.c = c;
         mf.len = e->d_len; mf.len_rw = e->d_len; mf.loop = e->d_loop; mf.rec_ring = e->d_loop_recs + k;
         int rc = hm_launch_argmin_tail(e, a, sqrt_c, thr, e->d_rec, true, 0, 0x7fffffff, true, mf, s);
@@ -118,10 +269,25 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
     }
     if (time_all) HM_HIP(hipEventRecord(e->loop_evs[2 * HM_LOOP_MAX_STEPS + 1], s));
     HM_HIP(hipMemcpyAsync(e->h->loop_recs, e->d_loop_recs, sizeof(ArgminRec) * (size_t)steps, hipMemcpyDeviceToHost, s));
+    if (piped) HM_HIP(hipMemcpyAsync(&e->h->ctr[7], &e->d_loop->stop, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HM_HIP(hipStreamSynchronize(s));
     hm_unpack_recs(e->h->loop_recs, steps, rec_out, done);
     e->n = n0 + *done;
-    e->armed = (*done == steps);
+    if (piped && *done < steps && e->h->ctr[7] == 5u) {
+        // a scan's order guard tripped (never seen outside the test hook): the steps from there on, strictly sequentially
+        e->armed = false;
+        e->pipe_fault_at = -1;
+        const bool keep = e->pipeline;
+        e->pipeline = false;
+        int64_t done2 = 0;
+        const int rc2 = hm_std_merge_steps(e, c, thr, X_dev, ld, steps - *done, rec_out + 4 * *done, &done2, stream);
+        e->pipeline = keep;
+        if (rc2) return rc2;
+        *done += done2;
+        return HM_OK;
+    }
+    e->pipe_fault_at = -1;
+    e->armed = (*done == steps) && !piped;         // (the pipelined batch leaves its two sets armed for ITS next steps only)
     e->armed_rb = 0; e->armed_re = -1;
     if (time_all) {
         e->last_batch_ms = e->last_batch_scan_ms = 0.f;

@@ -106,6 +106,10 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NBUF * TILE_LDS (+ hist)
 
     if (p.stop != nullptr && *p.stop != 0u) return;     // a device-resident loop has ended
+    if (p.order_seen != nullptr && __hip_atomic_load(p.order_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.order_need) {
+        if (threadIdx.x == 0) __hip_atomic_store(p.order_fault, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;                                         // (pipelined loop: inputs not written yet -- see ScanArgs)
+    }
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -665,7 +669,7 @@ static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, h
     // timed launches carry their events in the dispatch itself (start / stop timestamps of this kernel): a pair of
     // hipEventRecord calls around it costs two ~6 us bubbles on the stream
     const ScanArgs& b = a;
-    if (ev0 != nullptr) hipExtLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, ev0, ev1, 0, b);
+    if (ev0 != nullptr || ev1 != nullptr) hipExtLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, ev0, ev1, 0, b);
     else hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, b);
     return hipGetLastError();
 }

@@ -56,8 +56,9 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
     // ---- exact distance of this block's entries, lexicographic min of (d bits, i, j) with d < thr ----
     uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
     // a half-wave takes HM_GATHER consecutive entries per round (hm_halfwave_gather): lane t finishes entry t
-    const uint32_t hw = (blockIdx.x * HM_TAIL_THREADS + threadIdx.x) >> 5;          // half-wave id
-    const uint32_t stride = active * (HM_TAIL_THREADS >> 5) * HM_GATHER;
+    // (the block size is the launch's: 1024 threads, or 256 in the pipelined loop where the kernel has to fit beside a scan block)
+    const uint32_t hw = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;               // half-wave id
+    const uint32_t stride = active * (blockDim.x >> 5) * HM_GATHER;
     const int t32 = lane & 31;
     for (uint32_t base = (hw & ~1u) * HM_GATHER; base < m; base += stride) {             // wave-uniform trip count
         const uint32_t mybase = base + (hw & 1u) * HM_GATHER;
@@ -101,6 +102,14 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
         hm_block_min_key(b0, b1, b2, s0, s1, s2);
     }
 
+    // pipelined loop: the pairs of the newest row were searched by their own small kernel
+    if (a.mf.rowkey != nullptr) {
+        const unsigned long long rk = *a.mf.rowkey;
+        if (rk != ~0ull) {
+            const uint32_t db = (uint32_t)(rk >> 32), ri = (uint32_t)rk, rj = a.mf.rowkey_j;
+            if (hm_key_less(db, ri, rj, b0, b1, b2)) { b0 = db; b1 = ri; b2 = rj; }
+        }
+    }
     // ---- final (one block): record, seed, arming, merge ----
     // found = 2: the emission buffer overflowed, the record is not final (the caller reruns bounded)
     const uint32_t found = emitted > (unsigned long long)a.cap ? 2u : ((b1 != 0xffffffffu) ? 1u : 0u);
@@ -136,6 +145,7 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
         a.ctr64[0] = 0ull;
         a.ctr64[1] = use ? seed_key : ~0ull;
         a.ctr64[2] = 0ull;
+        if (a.mf.rowkey != nullptr) *a.mf.rowkey = ~0ull;
     }
     // ---- fused merge of the pair just found (device-resident loop) ----
     if (a.mf.X != nullptr) {
@@ -153,6 +163,7 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
             loop->stop = found == 2u ? 2u : 1u;
         }
     }
+    if (a.mf.rowkey != nullptr && loop != nullptr && lane == 0) loop->tails_done += 1u;      // (pipelined loop: the scans' order guard)
 }
 
 int hm_launch_argmin_tail(hm_engine* e, const ScanArgs& sa, float sqrt_c, float thr, ArgminRec* rec_out, bool with_seed,
@@ -160,7 +171,7 @@ int hm_launch_argmin_tail(hm_engine* e, const ScanArgs& sa, float sqrt_c, float 
 {
     TailArgs t;
     memset(&t, 0, sizeof(t));
-    t.ent = e->ent; t.ctr64 = e->d_ctr64; t.cap = e->ent_cap;
+    t.ent = mf.pipe_ent ? mf.pipe_ent : e->ent; t.ctr64 = mf.pipe_ctr64 ? mf.pipe_ctr64 : e->d_ctr64; t.cap = e->ent_cap;
     t.img = e->img; t.img16 = e->img16; t.RS = e->RS; t.d = e->d; t.KC = e->KC; t.sign_mode = e->sign_mode;
     t.sqrt_c = sqrt_c; t.thr = thr;
     t.parts = e->d_parts; t.ticket = e->d_ctr + 6;
@@ -169,7 +180,9 @@ int hm_launch_argmin_tail(hm_engine* e, const ScanArgs& sa, float sqrt_c, float 
     t.bf = sa.bf16; t.kterms = sa.bf16 ? 8 * e->KC : e->RS; t.rmax2_bits = e->d_rmax2;
     t.arm = arm ? 1 : 0; t.arm_rb = arm_rb; t.arm_re = arm_re;
     t.mf = mf;
-    hipLaunchKernelGGL(hm_argmin_tail_kernel, dim3(HM_TAIL_BLOCKS), dim3(HM_TAIL_THREADS), 0, s, t);
+    // Pipelined loop (mf.rowkey set): the kernel runs UNDER the next step's scan, whose two blocks per CU leave room for four
+    // more waves at most -- 256-thread blocks; otherwise 1024
+    hipLaunchKernelGGL(hm_argmin_tail_kernel, dim3(HM_TAIL_BLOCKS), dim3(mf.rowkey != nullptr ? 256 : HM_TAIL_THREADS), 0, s, t);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
@@ -190,7 +203,8 @@ __global__ void hm_seed_init_kernel(const ArgminSeed* __restrict__ seed, unsigne
 
 int hm_launch_seed_init(hm_engine* e, const ScanArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, e->d_ctr64, e->d_ctr, a.row_begin, a.row_end);
+    // (a.ctr64: the engine's first counter set, or the second one of the pipelined loop)
+    hipLaunchKernelGGL(hm_seed_init_kernel, dim3(1), dim3(64), 0, s, e->d_seed, a.ctr64, e->d_ctr, a.row_begin, a.row_end);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
@@ -728,7 +742,7 @@ static int hm_topk_core_form(hm_engine* e, float c, float thr, int64_t k, int64_
 // ------------------------------------------------------------------------------------------------
 // C ABI: searches
 // ------------------------------------------------------------------------------------------------
-static const MergeFuse kNoMerge = {nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr};
+static const MergeFuse kNoMerge = {nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
 
 extern "C" int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t row_begin, int64_t row_end, uint32_t* rec_dev,
                                       void* stream)

@@ -564,3 +564,33 @@ def test_loop_timing_mode_changes_nothing_but_the_statistics(oracle):
             eng.debug_time_loops(False)
     assert runs[0][1] == runs[1][1] == 20 and runs[0][0] == runs[1][0]
     assert torch.equal(runs[0][2].view(torch.int32), runs[1][2].view(torch.int32))
+
+
+def test_pipelined_loop_equals_sequential_loop_and_survives_an_order_fault():
+    """The standard loop's software pipeline (a step's tail work under the next step's scan, two buffer sets, the newest
+    row's pairs by a row pass) merges the same pairs into the same rows as the strictly sequential chain; a scan whose order
+    guard trips (forced here through the `pipe_fault_at` knob) hands the remaining steps to the sequential path."""
+    from hyptokenizer_amd import _lib
+    from hyptokenizer_amd.engine import MergeEngine
+    L = _lib.load()
+    n, d, steps = 9000, 48, 40
+    X = lorentz_table(n, d, seed=21, scale=0.05)
+    runs = []
+    for mode in ("seq", "pipe", "fault"):
+        table = torch.zeros((n + steps + 8, d + 1), device="cuda")
+        table[:n] = X.cuda()
+        eng = MergeEngine(n + steps + 8, d + 1, "lorentz")
+        _lib.check(L.hm_debug_set_knob(eng._h, b"pipeline", 0.0 if mode == "seq" else 1.0))
+        _lib.check(L.hm_debug_set_knob(eng._h, b"pipeline_pairs", 0.0))              # (pipelined at this small size too: tails longer than scans trip the guard by themselves)
+        if mode == "fault":
+            _lib.check(L.hm_debug_set_knob(eng._h, b"pipe_fault_at", 17.0))
+        eng.set_table(table, n)
+        eng.set_token_lengths(np.arange(1, n + 1, dtype=np.int32) % 5 + 1)
+        recs, done = eng.std_merge_steps(1.0, 0.6, table, steps)
+        assert done == steps, (mode, done)
+        # a second batch on the same engine (the sets are re-armed from the engine's seed)
+        recs2, done2 = eng.std_merge_steps(1.0, 0.6, table, 3) if n + steps + 3 <= table.shape[0] else ([], 0)
+        runs.append(([r[2:] for r in recs] + [r[2:] for r in recs2], [_bits([r[1]])[0] for r in recs], table[n:n + steps].cpu().numpy().view(np.uint32).copy(),
+                     eng.argmin(1.0, 0.6)))
+    for other in runs[1:]:
+        assert other[0] == runs[0][0] and other[1] == runs[0][1] and np.array_equal(other[2], runs[0][2]) and other[3] == runs[0][3]
