@@ -191,7 +191,7 @@ struct hm_engine {
     // software-pipelined standard loop: a second (high-priority) stream for the step's tail work, which then runs under
     // the NEXT step's scan; per buffer set an event behind the scan and one behind the tail; the new row's key per set
     bool pipeline = true;
-    int64_t pipeline_min_pairs = 400000000ll;   // (knob "pipeline_pairs")
+    int64_t pipeline_min_pairs = 800000000ll;   // (knob "pipeline_pairs"): ~40 000 rows -- a scan of 150 us against 50 us of tail work under it
     int pipe_fault_at = -1;              // test hook (knob "pipe_fault_at"): the scan of this step of the next batch is made to trip its order guard
     hipStream_t aux = nullptr;
     hipEvent_t ev_scan[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr}, ev_join = nullptr;

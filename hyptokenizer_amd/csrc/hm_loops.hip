@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64) void hm_newrow_key_kernel(const float* __restri
 {
     extern __shared__ __align__(16) float lds[];
     if (stop != nullptr && *stop != 0u) return;
+    __builtin_amdgcn_s_setprio(3);          // (runs beside the scan's MFMA waves)
     float* xs = lds;
     const int lane = threadIdx.x;
     float* tile = lds + HM_MAX_D1 + 4;
@@ -180,7 +181,7 @@ static int hm_std_merge_steps_pipelined(hm_engine* e, float c, float thr, const 
         if (k >= 1) {
             const int64_t row = e->n - 1;
             const int64_t nt = (row + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
-            hipLaunchKernelGGL(hm_newrow_key_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(nt, 256))), dim3(64), row_lds, sb, e->img, e->RS,
+            hipLaunchKernelGGL(hm_newrow_key_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(nt, 128))), dim3(64), row_lds, sb, e->img, e->RS,
                                e->d, row, sqrt_c, thr, e->sign_mode, e->d_rowkey + set, &e->d_loop->stop);
             HM_HIP(hipGetLastError());
         }
@@ -233,7 +234,7 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
     if (time_all) hm_read_loop_events(e);         // the events are about to be reused
     int64_t all_pairs[HM_LOOP_MAX_STEPS];
     // pipelined when a scan is long against a tail kernel (the tail of step k - 2 has to be through while scan k - 1 runs; the
-    // scans' order guard catches the rest): from ~28 000 rows of d = 100 on
+    // scans' order guard catches the rest): from ~40 000 rows on
     const bool piped = e->pipeline && steps >= 2 && hm_pairs_in_range(e->n, 0, e->n - 1) >= e->pipeline_min_pairs;
     if (piped) {
         const int rcp = hm_std_merge_steps_pipelined(e, c, thr, b, X_dev, ld, steps, s, all_pairs, time_all, &timed_pairs);

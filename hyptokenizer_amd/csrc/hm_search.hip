@@ -37,6 +37,7 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
     __shared__ uint32_t s_last;
     __shared__ MidScratch ms;
     const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_s_setprio(3);          // in the pipelined loop this latency-bound chain shares its SIMDs with the next scan's MFMA waves
     LoopState* loop = a.mf.loop;
     if (loop != nullptr && loop->stop != 0u) {                 // the loop ended at an earlier step: this one is skipped
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -182,7 +183,8 @@ int hm_launch_argmin_tail(hm_engine* e, const ScanArgs& sa, float sqrt_c, float 
     t.mf = mf;
     // Pipelined loop (mf.rowkey set): the kernel runs UNDER the next step's scan, whose two blocks per CU leave room for four
     // more waves at most -- 256-thread blocks; otherwise 1024
-    hipLaunchKernelGGL(hm_argmin_tail_kernel, dim3(HM_TAIL_BLOCKS), dim3(mf.rowkey != nullptr ? 256 : HM_TAIL_THREADS), 0, s, t);
+    // -- and four of them: every block of the grid has to find a slot before the kernel can end, whether it has entries or not
+    hipLaunchKernelGGL(hm_argmin_tail_kernel, dim3(mf.rowkey != nullptr ? 4 : HM_TAIL_BLOCKS), dim3(mf.rowkey != nullptr ? 256 : HM_TAIL_THREADS), 0, s, t);
     HM_HIP(hipGetLastError());
     return HM_OK;
 }
