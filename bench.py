@@ -245,12 +245,14 @@ def bandwidth_kernels(device) -> list:
     return out
 
 
-def config5_leg(device, steps: int = 200) -> dict:
+def config5_leg(device, steps: int = 24) -> dict:
     """BASELINE config 5 on one GPU: EnhancedFastHyperbolicTokenizer, frequency-aware scoring + adaptive curvature
     (V = 100 000, d = 100).  Per step: 100 cached candidates scored (torch.randperm(n) per candidate on the host, as the
     reference draws them; midpoint + 50 gathered distances per candidate in one fused kernel); one refresh scores every
-    candidate; 200 steps = two refresh cycles with the curvature step (class default: every 100 merges; analytic gradient,
-    the reference's raises) and its whole-table re-projection between them."""
+    candidate; the curvature step fires once (analytic gradient; the reference's raises).  A SHORT run on purpose:
+    the reference's loop keeps merged tokens in the table, so on this synthetic table it merges the same nearest pairs again
+    and again, the duplicates multiply the candidate list and every refresh scores every candidate (200 steps: 60 ms per step,
+    a refresh of 19 s -- the algorithm's own cost, measured in round 3)."""
     import random
     from hyptokenizer_amd.synthetic import cjk_vocab, lorentz_table
     from hyptokenizer_amd.tokenizer.enhanced_fast_hyperbolic_merge import EnhancedFastHyperbolicTokenizer
@@ -262,7 +264,7 @@ def config5_leg(device, steps: int = 200) -> dict:
     tok = EnhancedFastHyperbolicTokenizer(vocab, torch.nn.Parameter(X), curvature=CURV, merge_threshold=0.45, device=device,
                                           max_vocab_size=n5 + steps + 64, sign_convention="lorentz", use_frequency_aware=True,
                                           use_hierarchical=False, use_adaptive_curvature=True, use_compression_aware=False,
-                                          optimize_curvature_freq=100)          # (the class default: one curvature step per 100 merges)
+                                          optimize_curvature_freq=steps // 2)
     rs = np.random.RandomState(SEED)                  # synthetic pair-frequency table: Zipf(1.2) counts over random pairs
     a, b = rs.randint(0, n5, 200000), rs.randint(0, n5, 200000)
     cnt = rs.zipf(1.2, 200000).clip(max=10 ** 6)

@@ -53,6 +53,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define HM_TAIL_BLOCKS 32          // blocks of the argmin tail kernel (one is enough for <= HM_TAIL_SOLO entries)
 #define HM_TAIL_THREADS 1024
 #define HM_TAIL_SOLO 1024u
+#define HM_PIPE_TAIL_MAX 8192u     // survivors a pipelined step's small tail grid takes (more: found = 2, that step goes through the host path)
 #define HM_ROWPASS_BLOCKS 256      // blocks of the one-row-vs-all reduction
 #define HM_PART_SLOTS 256          // partial records (>= HM_TAIL_BLOCKS, HM_ROWPASS_BLOCKS)
 #define HM_LOOP_MAX_STEPS 256
@@ -132,7 +133,8 @@ struct HostCtl {                 // pinned host mirror of small device results
 
 // state of the device-resident merge loops (one per engine, in HBM)
 struct LoopState {
-    uint32_t stop;               // 0 running, 1 no candidate, 2 emission overflow, 5 pipelined loop: a scan started before its inputs were written
+    uint32_t stop;               // 0 running, 1 no candidate, 2 emission overflow, 5 pipelined loop: a scan started before its inputs were
+                                 // written, 6 pipelined loop: more survivors than its small tail grid takes
     uint32_t steps_done;
     // incremental loop: running nearest pair, double-buffered by step parity: the blocks of step k read best[k & 1]
     // (written by the previous launch, or by the host for k = 0) and block 0 writes the folded value to best[(k + 1) & 1]

@@ -287,6 +287,27 @@ extern "C" int hm_std_merge_steps(hm_engine* e, float c, float thr, float* X_dev
         *done += done2;
         return HM_OK;
     }
+    if (piped && *done < steps && e->h->ctr[7] == 6u) {
+        // a step left more survivors than the pipelined tail's small grid takes (typically the first search on a new table,
+        // before a seed bounds the emissions): that ONE step through the sequential chain and its full-size tail, the rest
+        // pipelined again
+        e->armed = false;
+        const bool keep = e->pipeline;
+        e->pipeline = false;
+        int64_t done2 = 0;
+        int rc2 = hm_std_merge_steps(e, c, thr, X_dev, ld, 1, rec_out + 4 * *done, &done2, stream);
+        e->pipeline = keep;
+        if (rc2) return rc2;
+        *done += done2;
+        if (done2 == 1 && *done < steps) {
+            const int64_t before = *done;
+            int64_t done3 = 0;
+            rc2 = hm_std_merge_steps(e, c, thr, X_dev, ld, steps - before, rec_out + 4 * before, &done3, stream);
+            if (rc2) return rc2;
+            *done = before + done3;
+        }
+        return HM_OK;
+    }
     e->pipe_fault_at = -1;
     e->armed = (*done == steps) && !piped;         // (the pipelined batch leaves its two sets armed for ITS next steps only)
     e->armed_rb = 0; e->armed_re = -1;

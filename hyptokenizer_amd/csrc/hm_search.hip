@@ -48,7 +48,12 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
         return;
     }
     const unsigned long long emitted = a.ctr64[2];
-    const uint32_t m = emitted > (unsigned long long)a.cap ? a.cap : (uint32_t)emitted;
+    // (an overflowed search reports found = 2 whatever its entries say: none of them is read.  The pipelined loop's small
+    // tail grid -- it runs beside a scan -- hands a step with more than HM_PIPE_TAIL_MAX survivors back the same way: the
+    // host redoes that one step through hm_pairwise_argmin and its full-size tail)
+    const bool over_small = a.mf.rowkey != nullptr && emitted <= (unsigned long long)a.cap && emitted > (unsigned long long)HM_PIPE_TAIL_MAX;
+    const bool over = emitted > (unsigned long long)a.cap || over_small;
+    const uint32_t m = over ? 0u : (uint32_t)emitted;
     uint32_t active = (m + HM_TAIL_SOLO - 1) / HM_TAIL_SOLO;       // HM_TAIL_SOLO = entries one block takes per two rounds
     if (active < 1) active = 1;
     if (active > gridDim.x) active = gridDim.x;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
     }
     // ---- final (one block): record, seed, arming, merge ----
     // found = 2: the emission buffer overflowed, the record is not final (the caller reruns bounded)
-    const uint32_t found = emitted > (unsigned long long)a.cap ? 2u : ((b1 != 0xffffffffu) ? 1u : 0u);
+    const uint32_t found = over ? 2u : ((b1 != 0xffffffffu) ? 1u : 0u);
     if (threadIdx.x >= 64) return;                              // wave 0 finishes (b0, b1, b2 are block-uniform)
     const uint32_t bi = b1, bj = b2;
     if (lane == 0) {
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(HM_TAIL_THREADS) void hm_argmin_tail_kernel(const T
                 if (loop) loop->steps_done += 1u;
             }
         } else if (loop != nullptr && lane == 0) {
-            loop->stop = found == 2u ? 2u : 1u;
+            loop->stop = found == 2u ? (over_small ? 6u : 2u) : 1u;       // (6: too many survivors for the pipelined loop's tail grid only)
         }
     }
     if (a.mf.rowkey != nullptr && loop != nullptr && lane == 0) loop->tails_done += 1u;      // (pipelined loop: the scans' order guard)
