@@ -173,6 +173,7 @@ struct hm_engine {
     uint32_t ent_cap = 0;
     uint32_t* d_ctr = nullptr;            // 8 x u32 (post-kernel counters)
     uint32_t* d_rmax2 = nullptr;
+    uint32_t* d_rmax2_mem = nullptr;            // the allocation: two pairs; d_rmax2 = the live one, the other is kept zeroed (hm_project_table swaps them)
     unsigned long long* d_ctr64 = nullptr; // 4 x u64
     ArgminRec* d_rec = nullptr;            // 2 records
     ArgminRec* d_loop_recs = nullptr;      // HM_LOOP_MAX_STEPS records
@@ -197,7 +198,7 @@ struct hm_engine {
     int pipe_fault_at = -1;              // test hook (knob "pipe_fault_at"): the scan of this step of the next batch is made to trip its order guard
     hipStream_t aux = nullptr;
     hipEvent_t ev_scan[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr}, ev_join = nullptr;
-    unsigned long long* d_rowkey = nullptr;     // 2 keys
+    unsigned long long* d_rowkey = nullptr;     // [0], [1]: the pipelined loop's two sets; [2]: hm_row_argmin
     // cut prediction for top-k: valid while rows are only appended
     bool have_cut = false;
     uint32_t last_cut_bits = 0;
@@ -306,6 +307,7 @@ struct MergeFuse {
     uint32_t rowkey_j;
 };
 int hm_launch_seed_init(hm_engine* e, const ScanArgs& a, hipStream_t s);
+int hm_launch_row_key(hm_engine* e, int64_t row, int64_t n_partners, float sqrt_c, float thr, unsigned long long* key_dev, hipStream_t s);   // hm_loops.hip
 int hm_launch_argmin_tail(hm_engine* e, const ScanArgs& a, float sqrt_c, float thr, ArgminRec* rec_out, bool with_seed,
                           int arm_rb, int arm_re, bool arm, const MergeFuse& mf, hipStream_t s);
 
@@ -410,6 +412,14 @@ __device__ __forceinline__ float hm_halfwave_gather(int lane, UF u_of)
         mine = (t == k) ? u : mine;
     }
     return mine;
+}
+
+// atomicMax on a word that MANY blocks raise towards the same value (the norm bounds): same-address device-scope atomics
+// serialise at the memory side (~10 ns each: 1 500 of them cost more than the kernel around them), so a wave first reads the
+// word (device scope, fresh) and only sends the atomic when it would raise it -- ~ln(blocks) atomics instead of one per block
+__device__ __forceinline__ void hm_raise_bits(uint32_t* word, uint32_t bits)
+{
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(word, bits);
 }
 
 __device__ __forceinline__ bool hm_key_less(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2)

@@ -114,12 +114,13 @@ static int hm_engine_alloc(hm_engine* e)
     HM_HIP(hipEventCreateWithFlags(&e->ev_batch, hipEventDisableTiming));
     HM_HIP(hipMalloc(&e->d_ctr, sizeof(uint32_t) * 8));
     HM_HIP(hipMemset(e->d_ctr, 0, sizeof(uint32_t) * 8));
-    HM_HIP(hipMalloc(&e->d_rmax2, sizeof(uint32_t) * 2));
-    HM_HIP(hipMemset(e->d_rmax2, 0, sizeof(uint32_t) * 2));
+    HM_HIP(hipMalloc(&e->d_rmax2_mem, sizeof(uint32_t) * 4));
+    HM_HIP(hipMemset(e->d_rmax2_mem, 0, sizeof(uint32_t) * 4));
+    e->d_rmax2 = e->d_rmax2_mem;
     HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 8));            // two sets of 4 (the second: pipelined loop)
     HM_HIP(hipMemset(e->d_ctr64, 0, sizeof(unsigned long long) * 8));
-    HM_HIP(hipMalloc(&e->d_rowkey, sizeof(unsigned long long) * 2));
-    HM_HIP(hipMemset(e->d_rowkey, 0xff, sizeof(unsigned long long) * 2));
+    HM_HIP(hipMalloc(&e->d_rowkey, sizeof(unsigned long long) * 3));
+    HM_HIP(hipMemset(e->d_rowkey, 0xff, sizeof(unsigned long long) * 3));
     HM_HIP(hipMalloc(&e->d_seed, sizeof(ArgminSeed)));
     HM_HIP(hipMemset(e->d_seed, 0, sizeof(ArgminSeed)));
     HM_HIP(hipMalloc(&e->d_rec, 2 * sizeof(ArgminRec)));
@@ -206,7 +207,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     if (!e) return HM_OK;
     (void)hipSetDevice(e->device);
     (void)hm_comm_destroy(e);
-    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2, e->d_parts,
+    void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2_mem, e->d_parts,
                         e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch, e->d_rowkey};
     for (void* q : dev_ptrs)
         if (q) (void)hipFree(q);

@@ -72,9 +72,11 @@ static void hm_unpack_recs(const ArgminRec* recs, int64_t steps, uint32_t* rec_o
 // k + 2 with the seed of step k (the pair it merged from still exists: a valid bound).  Every pair is still evaluated in
 // every step; results are bit-identical to the sequential chain (tests run both).
 
-// nearest partner of image row `row` among rows [0, row): (bits(d) << 32) | i folded into *key by atomicMin (d < thr)
-__global__ __launch_bounds__(64) void hm_newrow_key_kernel(const float* __restrict__ img, int RS, int d, int64_t row, float sqrt_c, float thr,
-                                                           int sign_mode, unsigned long long* __restrict__ key, const uint32_t* __restrict__ stop)
+// nearest partner of image row `row` among rows [0, n_partners) other than itself: (bits(d) << 32) | i folded into *key by
+// atomicMin (d < thr).  Row tiles: a wave copies 64 consecutive image rows to LDS, then one lane per row (hm_rows_device.h).
+__global__ __launch_bounds__(64) void hm_newrow_key_kernel(const float* __restrict__ img, int RS, int d, int64_t row, int64_t n_partners,
+                                                           float sqrt_c, float thr, int sign_mode, unsigned long long* __restrict__ key,
+                                                           const uint32_t* __restrict__ stop)
 {
     extern __shared__ __align__(16) float lds[];
     if (stop != nullptr && *stop != 0u) return;
@@ -82,10 +84,10 @@ __global__ __launch_bounds__(64) void hm_newrow_key_kernel(const float* __restri
     float* xs = lds;
     const int lane = threadIdx.x;
     float* tile = lds + HM_MAX_D1 + 4;
-    const int64_t nt = (row + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
+    const int64_t nt = (n_partners + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
     int64_t tl = blockIdx.x;
     TileRegs tr;
-    if (tl < nt) hm_tile_load(img, RS, tl * HM_TILE_ROWS, row, tr, lane);
+    if (tl < nt) hm_tile_load(img, RS, tl * HM_TILE_ROWS, n_partners, tr, lane);
     for (int k = lane; k < RS; k += 64) xs[k] = img[row * RS + k];
     hm_wave_lds_sync();
     unsigned long long best = ~0ull;
@@ -93,11 +95,11 @@ __global__ __launch_bounds__(64) void hm_newrow_key_kernel(const float* __restri
         hm_tile_store(tile, RS, tr, lane);
         hm_wave_lds_sync();
         const int64_t nxt = tl + gridDim.x;
-        if (nxt < nt) hm_tile_load(img, RS, nxt * HM_TILE_ROWS, row, tr, lane);
+        if (nxt < nt) hm_tile_load(img, RS, nxt * HM_TILE_ROWS, n_partners, tr, lane);
         const float u = hm_tile_u(tile, RS, d, xs, sign_mode, lane);
         const int64_t i = tl * HM_TILE_ROWS + lane;
         const float dd = hm::dist_from_u(u, sqrt_c);
-        if (i < row && dd < thr) {
+        if (i < n_partners && i != row && dd < thr) {
             const unsigned long long k64 = ((unsigned long long)hm::fbits(dd) << 32) | (unsigned long long)(uint32_t)i;
             best = k64 < best ? k64 : best;
         }
@@ -105,6 +107,34 @@ __global__ __launch_bounds__(64) void hm_newrow_key_kernel(const float* __restri
     }
     best = hm_wave_min_u64(best);
     if (lane == 0 && best != ~0ull) atomicMin(key, best);
+}
+
+// dynamic LDS of hm_newrow_key_kernel (the fixed row + one tile), with the kernel's limit raised once per engine
+static int hm_row_key_lds(hm_engine* e, size_t* bytes)
+{
+    const void* kfn = reinterpret_cast<const void*>(&hm_newrow_key_kernel);
+    *bytes = sizeof(float) * ((size_t)HM_MAX_D1 + 4 + (size_t)HM_TILE_ROWS * e->RS);
+    if (e->attr_done.find(kfn) == e->attr_done.end()) {
+        HM_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(float) * ((size_t)HM_MAX_D1 + 4 + (size_t)HM_TILE_ROWS * 4 * HM_TILE_MAXQ))));
+        e->attr_done.insert(kfn);
+    }
+    return HM_OK;
+}
+
+// hm_row_argmin's device part: *key_dev (pre-set to all ones) <- min over rows i in [0, n_partners), i != row, d(row, i) < thr of
+// (bits(d) << 32) | i.  Ordering by (bits, i) IS the engine's (bits, min(i,row), max(i,row)) order: partners below `row` sort
+// before partners above it (their smaller index is i < row) and both groups sort by i.
+int hm_launch_row_key(hm_engine* e, int64_t row, int64_t n_partners, float sqrt_c, float thr, unsigned long long* key_dev, hipStream_t s)
+{
+    size_t row_lds = 0;
+    int rc = hm_row_key_lds(e, &row_lds);
+    if (rc) return rc;
+    const int64_t nt = (n_partners + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
+    hipLaunchKernelGGL(hm_newrow_key_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(nt, 1024))), dim3(64), row_lds, s, e->img, e->RS,
+                       e->d, row, n_partners, sqrt_c, thr, e->sign_mode, key_dev, (const uint32_t*)nullptr);
+    HM_HIP(hipGetLastError());
+    return HM_OK;
 }
 
 static int hm_pipeline_init(hm_engine* e)
@@ -133,13 +163,9 @@ static int hm_std_merge_steps_pipelined(hm_engine* e, float c, float thr, const 
     HM_HIP(hipMemsetAsync(e->d_rowkey, 0xff, sizeof(unsigned long long) * 2, s));
     HM_HIP(hipEventRecord(e->ev_join, s));
     HM_HIP(hipStreamWaitEvent(sb, e->ev_join, 0));
-    const void* kfn = reinterpret_cast<const void*>(&hm_newrow_key_kernel);
-    const size_t row_lds = sizeof(float) * ((size_t)HM_MAX_D1 + 4 + (size_t)HM_TILE_ROWS * e->RS);
-    if (e->attr_done.find(kfn) == e->attr_done.end()) {
-        HM_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(sizeof(float) * ((size_t)HM_MAX_D1 + 4 + (size_t)HM_TILE_ROWS * 4 * HM_TILE_MAXQ))));
-        e->attr_done.insert(kfn);
-    }
+    size_t row_lds = 0;
+    rc = hm_row_key_lds(e, &row_lds);
+    if (rc) return rc;
     for (int64_t k = 0; k < steps; ++k) {
         const int set = (int)(k & 1);
         e->n = n0 + k;                                   // rows of step k's table (optimistic: corrected by the caller when the batch stops early)
@@ -182,7 +208,7 @@ static int hm_std_merge_steps_pipelined(hm_engine* e, float c, float thr, const 
             const int64_t row = e->n - 1;
             const int64_t nt = (row + HM_TILE_ROWS - 1) / HM_TILE_ROWS;
             hipLaunchKernelGGL(hm_newrow_key_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(nt, 128))), dim3(64), row_lds, sb, e->img, e->RS,
-                               e->d, row, sqrt_c, thr, e->sign_mode, e->d_rowkey + set, &e->d_loop->stop);
+                               e->d, row, row, sqrt_c, thr, e->sign_mode, e->d_rowkey + set, &e->d_loop->stop);
             HM_HIP(hipGetLastError());
         }
         HM_HIP(hipStreamWaitEvent(sb, ev_stop, 0));

@@ -51,8 +51,8 @@ __global__ void hm_rownorm_kernel(const float* __restrict__ img, int RS, int64_t
         s2 = __builtin_fmaxf(s2, __shfl_xor(s2, off, 64));
     }
     if ((threadIdx.x & 63) == 0) {
-        if (r2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(r2));
-        if (s2 > 0.0f) atomicMax(rmax2_bits + 1, hm::fbits(s2));
+        if (r2 > 0.0f) hm_raise_bits(rmax2_bits, hm::fbits(r2));
+        if (s2 > 0.0f) hm_raise_bits(rmax2_bits + 1, hm::fbits(s2));
     }
 }
 
@@ -249,14 +249,42 @@ __global__ __launch_bounds__(256) void hm_coherence_kernel(const float* __restri
 // (the canonical order of project is sequential) on LDS operands.
 __global__ __launch_bounds__(64) void hm_project_table_kernel(float* __restrict__ X, int64_t ld, int d, int64_t n_rows, float c,
                                                               float* __restrict__ img, int RS, unsigned char* __restrict__ img16, int KC,
-                                                              int64_t n_live, uint32_t* __restrict__ rmax2_bits)
+                                                              int64_t n_live, uint32_t* __restrict__ rmax2_bits,
+                                                              uint32_t* __restrict__ retired_bits, ArgminSeed* __restrict__ seed)
 {
-    extern __shared__ float tile[];                           // 64 x stride
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                // nothing on this stream reads them before the kernel ends
+        retired_bits[0] = 0u; retired_bits[1] = 0u;
+        ArgminSeed z; z.key = 0ull; z.i = 0u; z.valid = 0u;
+        *seed = z;
+    }
+    extern __shared__ __align__(16) float tile[];             // 64 x stride
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int rows = (int)(n_rows - r0 < 64 ? n_rows - r0 : 64);
     const int lane = threadIdx.x;
     int stride, first;
-    if (ld == d + 1) {                                        // the reference's layout: rows back to back -> one flat copy
+    if (ld == d + 1 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0) {
+        // the reference's layout: rows back to back -> one flat copy of 64 * ld floats (a multiple of 16 bytes from a 16-byte
+        // aligned start: r0 is a multiple of 64), as 16-byte loads that are ALL in flight before the first one is stored
+        stride = (int)ld; first = 1;
+        const float* src = X + r0 * ld;
+        const int total = rows * (int)ld, nvec = total >> 2;
+        const uint4* src4 = reinterpret_cast<const uint4*>(src);
+        TileRegs tr;
+#pragma unroll
+        for (int i = 0; i < HM_TILE_MAXQ; ++i) {
+            const int q = lane + 64 * i;
+            tr.q[i] = q < nvec ? src4[q] : make_uint4(0, 0, 0, 0);
+        }
+        float rem = 0.0f;
+        if (lane < (total & 3)) rem = src[4 * nvec + lane];
+        uint4* dst4 = reinterpret_cast<uint4*>(tile);
+#pragma unroll
+        for (int i = 0; i < HM_TILE_MAXQ; ++i) {
+            const int q = lane + 64 * i;
+            if (q < nvec) dst4[q] = tr.q[i];
+        }
+        if (lane < (total & 3)) tile[4 * nvec + lane] = rem;
+    } else if (ld == d + 1) {
         stride = (int)ld; first = 1;
         const float* src = X + r0 * ld;
         const int total = rows * (int)ld;
@@ -272,9 +300,17 @@ __global__ __launch_bounds__(64) void hm_project_table_kernel(float* __restrict_
     __syncthreads();
     float r2 = 0.0f, x0 = 0.0f;
     if (lane < rows) {
-        const float* tr = tile + lane * stride + first;
-#pragma unroll 4
-        for (int k = 0; k < d; ++k) r2 = __builtin_fmaf(tr[k], tr[k], r2);
+        const float* rowp = tile + lane * stride + first;
+        // the canonical order of project is ONE sequential fmaf chain; its operands are fetched sixteen at a time
+        int k = 0;
+        for (; k + 16 <= d; k += 16) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = rowp[k + q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) r2 = __builtin_fmaf(v[q], v[q], r2);
+        }
+        for (; k < d; ++k) r2 = __builtin_fmaf(rowp[k], rowp[k], r2);
         const float rr = __builtin_sqrtf(r2);
         x0 = __builtin_sqrtf(1.0f + (c * rr) * rr);
         const int64_t row = r0 + lane;
@@ -303,8 +339,8 @@ __global__ __launch_bounds__(64) void hm_project_table_kernel(float* __restrict_
         r2 = __builtin_fmaxf(r2, __shfl_xor(r2, off, 64));
     }
     if (lane == 0) {
-        if (q2 > 0.0f) atomicMax(rmax2_bits, hm::fbits(q2 * 1.0001f));
-        if (r2 > 0.0f) atomicMax(rmax2_bits + 1, hm::fbits(r2 * 1.0001f));
+        if (q2 > 0.0f) hm_raise_bits(rmax2_bits, hm::fbits(q2 * 1.0001f));
+        if (r2 > 0.0f) hm_raise_bits(rmax2_bits + 1, hm::fbits(r2 * 1.0001f));
     }
 }
 
@@ -565,16 +601,17 @@ extern "C" int hm_project_table(hm_engine* e, float* X_dev, int64_t ld, int64_t 
     hipStream_t s = (hipStream_t)stream;
     HM_HIP(hipSetDevice(e->device));
     if (n_rows == 0) return HM_OK;
-    HM_HIP(hipMemsetAsync(e->d_rmax2, 0, sizeof(uint32_t) * 2, s));
+    // ONE dispatch: the norm bounds are rebuilt in the engine's spare (zeroed) pair, which becomes the live one; the kernel
+    // zeroes the old pair (the next spare) and the argmin seed (every live row changed) on the side
+    uint32_t* fresh = e->d_rmax2 == e->d_rmax2_mem ? e->d_rmax2_mem + 2 : e->d_rmax2_mem;
     const size_t lds = sizeof(float) * 64 * (size_t)(e->d + 2);
     hipLaunchKernelGGL(hm_project_table_kernel, dim3((unsigned)((n_rows + 63) / 64)), dim3(64), lds, s, X_dev, ld, e->d, n_rows, c,
-                       e->img, e->RS, e->img16, e->KC, e->n, e->d_rmax2);
+                       e->img, e->RS, e->img16, e->KC, e->n, fresh, e->d_rmax2, e->d_seed);
     HM_HIP(hipGetLastError());
-    // every live row changed
+    e->d_rmax2 = fresh;
     e->armed = false;
     e->have_cut = false;
     e->topk_f32_thr = 0.0f;
-    HM_HIP(hipMemsetAsync(e->d_seed, 0, sizeof(ArgminSeed), s));
     return HM_OK;
 }
 

@@ -6,7 +6,7 @@
 
 // LDS scratch of one wave: the two operand rows, the scaled tangent and the result, in the reference's column
 // order (column 0 = time).
-struct MidScratch { float sx[HM_MAX_D1], sy[HM_MAX_D1], sv[HM_MAX_D1], so[HM_MAX_D1 + 12]; };
+struct MidScratch { float sx[HM_MAX_D1], sy[HM_MAX_D1], sv[HM_MAX_D1], so[HM_MAX_D1 + 36]; };
 
 __device__ __forceinline__ void hm_wave_lds_sync()
 {
@@ -50,19 +50,20 @@ __device__ __forceinline__ float hm_wave_midpoint(int d, float w, float c, int s
     float ch, sh;
     hm::cosh_sinh_c(nn, ch, sh);                               // cosh_c / sinh_c with their common expm1 evaluated once
     for (int k = lane; k <= d; k += 64) ms.so[k] = ch * ms.sx[k] + sh * (ms.sv[k] / nn);
-    if (lane < 8) ms.so[d + 1 + lane] = 0.0f;                  // zero tail: the chain below runs in steps of 8
+    if (lane < 32) ms.so[d + 1 + lane] = 0.0f;                 // zero tail: the chain below runs in steps of 32
     hm_wave_lds_sync();
     float r2 = 0.0f;
     if (project) {
         // project (:41-56): the canonical order is a sequential fmaf chain over k = 1..d; every lane runs it on LDS
-        // broadcast reads, eight operands fetched per step (fmaf(0, 0, r2) == r2: the zero tail does not change it)
+        // broadcast reads, 32 operands fetched per step so that the chain waits for LDS d / 32 times, not d / 8 times
+        // (fmaf(0, 0, r2) == r2: the zero tail does not change it)
 #pragma unroll 1
-        for (int k0 = 1; k0 <= d; k0 += 8) {
-            float v[8];
+        for (int k0 = 1; k0 <= d; k0 += 32) {
+            float v[32];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = ms.so[k0 + q];
+            for (int q = 0; q < 32; ++q) v[q] = ms.so[k0 + q];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) r2 = __builtin_fmaf(v[q], v[q], r2);
+            for (int q = 0; q < 32; ++q) r2 = __builtin_fmaf(v[q], v[q], r2);
         }
         const float rr = __builtin_sqrtf(r2);
         const float x0 = __builtin_sqrtf(1.0f + (c * rr) * rr);

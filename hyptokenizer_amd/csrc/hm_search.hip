@@ -217,70 +217,6 @@ int hm_launch_seed_init(hm_engine* e, const ScanArgs& a, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------
-// one-row-vs-all reduction (K3 + min): nearest partner of image row `row` among rows [0, n_partners)
-// ------------------------------------------------------------------------------------------------
-// A half-wave per partner row; the new row's elements stay in registers (element e of lane t: e = t, t + 32, ...).
-// Block b owns the rows congruent to its slice, so that with the hardware's round-robin placement every XCD keeps
-// re-reading the same eighth of the image (it stays in that XCD's L2 from one merge to the next).
-__device__ __forceinline__ void hm_rowpass_block(const float* __restrict__ img, int RS, int d, int sign_mode, int64_t row,
-                                                 int64_t n_partners, float sqrt_c, float thr, uint32_t& b0, uint32_t& b1, uint32_t& b2)
-{
-    const int lane = threadIdx.x & 63, t = lane & 31;
-    const int64_t nhw = ((int64_t)gridDim.x * blockDim.x) >> 5;
-    const int64_t hw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
-    for (int64_t base = (hw & ~(int64_t)1) * HM_GATHER; base < n_partners; base += nhw * HM_GATHER) {
-        const int64_t mybase = base + (hw & 1) * HM_GATHER;
-        const float u = hm_halfwave_gather(lane, [&](int k) {
-            const int64_t r = mybase + k < n_partners ? mybase + k : n_partners - 1;
-            return hm_img_u_halfwave(img, RS, d, row, r, sign_mode, lane);
-        });
-        const int64_t i = mybase + t;
-        const float dd = hm::dist_from_u(u, sqrt_c);
-        if (t < HM_GATHER && i < n_partners && i != row && dd < thr) {
-            const uint32_t lo = (uint32_t)(i < row ? i : row), hi = (uint32_t)(i < row ? row : i);
-            const uint32_t db = hm::fbits(dd);
-            if (hm_key_less(db, lo, hi, b0, b1, b2)) { b0 = db; b1 = lo; b2 = hi; }
-        }
-    }
-}
-
-__global__ __launch_bounds__(512) void hm_row_argmin_kernel(const float* __restrict__ img, int RS, int d, int sign_mode, int64_t row,
-                                                            int64_t n_partners, float sqrt_c, float thr, ArgminPart* __restrict__ parts,
-                                                            uint32_t* __restrict__ ticket, ArgminRec* __restrict__ out)
-{
-    __shared__ uint32_t s0[8], s1[8], s2[8];
-    __shared__ uint32_t s_last;
-    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu, b2 = 0xffffffffu;
-    hm_rowpass_block(img, RS, d, sign_mode, row, n_partners, sqrt_c, thr, b0, b1, b2);
-    hm_block_min_key(b0, b1, b2, s0, s1, s2);
-    if (threadIdx.x == 0) {
-        ArgminPart pt; pt.dbits = b0; pt.i = b1; pt.j = b2; pt.pad = 0;
-        parts[blockIdx.x] = pt;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (tk == gridDim.x - 1) ? 1u : 0u;
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *ticket = 0u;
-        }
-    }
-    __syncthreads();
-    if (s_last == 0u) return;
-    b0 = b1 = b2 = 0xffffffffu;
-    if (threadIdx.x < gridDim.x) {
-        const ArgminPart pt = parts[threadIdx.x];
-        b0 = pt.dbits; b1 = pt.i; b2 = pt.j;
-    }
-    hm_block_min_key(b0, b1, b2, s0, s1, s2);
-    if (threadIdx.x == 0) {
-        ArgminRec r; r.found = (b1 != 0xffffffffu) ? 1u : 0u; r.dbits = b0; r.i = b1; r.j = b2;
-        *out = r;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // top-k: exact distances of the emitted entries
 // ------------------------------------------------------------------------------------------------
 // entries {bits(u_f'), i, j, sure} -> {dbits | 0xffffffff, i, j, bits(u_c')} with the canonical distance.
@@ -1127,14 +1063,18 @@ extern "C" int hm_row_argmin(hm_engine* e, int64_t row, int64_t n_partners, floa
     HM_HIP(hipSetDevice(e->device));
     *found = 0; *d = 0.f; *i = -1; *j = -1;
     if (!(thr > 0.0f) || n_partners == 0) return HM_OK;
-    hipLaunchKernelGGL(hm_row_argmin_kernel, dim3(HM_ROWPASS_BLOCKS), dim3(512), 0, s, e->img, e->RS, e->d, e->sign_mode, row,
-                       n_partners, sqrtf(c), thr, e->d_parts, e->d_ctr + 7, e->d_rec);
-    HM_HIP(hipGetLastError());
-    HM_HIP(hipMemcpyAsync(&e->h->rec, e->d_rec, sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
+    // row tiles (hm_newrow_key_kernel, the pipelined loop's row pass): one 64-bit key folded by atomicMin
+    unsigned long long* key = e->d_rowkey + 2;
+    HM_HIP(hipMemsetAsync(key, 0xff, sizeof(unsigned long long), s));
+    int rc = hm_launch_row_key(e, row, n_partners, sqrtf(c), thr, key, s);
+    if (rc) return rc;
+    HM_HIP(hipMemcpyAsync(&e->h->ctr64[3], key, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HM_HIP(hipStreamSynchronize(s));
-    if (e->h->rec.found == 1u) {
-        union { uint32_t u; float f; } cv; cv.u = e->h->rec.dbits;
-        *found = 1; *d = cv.f; *i = (int32_t)e->h->rec.i; *j = (int32_t)e->h->rec.j;
+    const unsigned long long k64 = e->h->ctr64[3];
+    if (k64 != ~0ull) {
+        union { uint32_t u; float f; } cv; cv.u = (uint32_t)(k64 >> 32);
+        const int64_t p = (int64_t)(uint32_t)k64;
+        *found = 1; *d = cv.f; *i = (int32_t)(p < row ? p : row); *j = (int32_t)(p < row ? row : p);
     }
     return HM_OK;
 }

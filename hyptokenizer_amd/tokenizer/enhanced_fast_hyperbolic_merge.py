@@ -582,7 +582,7 @@ class EnhancedFastHyperbolicTokenizer(FastHyperbolicTokenizer):
                 if i >= rows or j >= rows:
                     continue
                 take = min(10, rows - 2)
-                smp = torch.randperm(rows)[:take]
+                smp = torch.from_numpy(randperm_prefixes(rows, take, 1)[0].astype(np.int64))      # = torch.randperm(rows)[:take], same generator state after
                 smp = smp[~torch.isin(smp, torch.tensor([i, j]))].tolist()
                 if not smp:
                     continue
