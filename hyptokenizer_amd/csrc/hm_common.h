@@ -43,7 +43,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ------------------------------------------------------------------------------------------------
 #define HM_MAX_BLOCK_ROWS 1024
 #define HM_MAX_D1 132              // largest table width (d + 1 <= 129) rounded up
-#define HM_TIE_SLACK 1024u         // ulps of u' that are treated as "may still order before" (d is 2.5-ulp monotone)
+#define HM_TIE_SLACK 1024u         // ulps of u' that are treated as "may still order before" for u' >= 2 (see hm_tie_slack)
 #define HM_MODE_TOPK 0
 #define HM_MODE_ARGMIN 1
 #define HM_MODE_HIST 2
@@ -414,6 +414,18 @@ __device__ __forceinline__ float hm_halfwave_gather(int lane, UF u_of)
     return mine;
 }
 
+// How many ulps of u' above a key may still order BEFORE it by computed distance: d = acosh(u') / sqrt(c) is monotone in u' only
+// up to the few-ulp error of acosh (2.5 ulps of d), so a pair at u' + s certainly has the larger d once the true increase
+// s * ulp(u') / sqrt(u'^2 - 1) exceeds ~5 ulps of d.  For large u' (d ~ ln 2u') that takes up to 16 d ~ hundreds of ulps of u'
+// -- HM_TIE_SLACK; near u' = 1 (d ~ sqrt(2 (u' - 1)), steep) a handful do: with t = u' - 1 < 1 the condition is s > ~20 t.
+// 32 + 128 t is used below u' = 2.  (A constant 1024 made the exact top-1 search of a very dense table impossible: at d = 5,
+// scale 0.01 there are ~10^5 pairs per ulp of u' -- round-3 fuzz.)  Non-decreasing in the bits.
+__host__ __device__ __forceinline__ uint32_t hm_tie_slack(uint32_t ubits)
+{
+    if (ubits >= 0x40000000u) return HM_TIE_SLACK;
+    return 32u + ((ubits > 0x3f800000u ? ubits - 0x3f800000u : 0u) >> 16);
+}
+
 // atomicMax on a word that MANY blocks raise towards the same value (the norm bounds): same-address device-scope atomics
 // serialise at the memory side (~10 ns each: 1 500 of them cost more than the kernel around them), so a wave first reads the
 // word (device scope, fresh) and only sends the atomic when it would raise it -- ~ln(blocks) atomics instead of one per block
@@ -458,14 +470,17 @@ __device__ __forceinline__ void hm_block_min_key(uint32_t& b0, uint32_t& b1, uin
 
 // Bound on |u_f - u_c| between the MFMA prefilter value and the canonical value of the same pair
 // (gamma_n bounds on both roundings, |terms| <= rmax2).  `kterms` = fp32 form: floats per image row;
-// bf16 form: 16 * k-steps.  bf16 operands: each spatial product carries <= 2 * 2^-9 (+ 2^-18) relative
-// error, so the sum is off by <= 2^-8 (1 + 2^-9) ||x_s|| ||y_s|| <= 0.00392 * (largest squared spatial
-// norm); the hi+lo split of the time coordinate leaves <= 2^-15 * x0*y0 (x0^2 <= rmax2).
+// bf16 form: 16 * k-steps.  bf16 operands: round-to-nearest to 8 significant bits is a relative error of at most
+// 2^-8 PER OPERAND, so each spatial product carries <= 2 * 2^-8 + 2^-16 and the sum is off by at most
+// 0.0078128 ||x_s|| ||y_s|| <= 0.00782 * (largest squared spatial norm).  (Rounds 1-2 used 0.00392 -- the error of ONE
+// operand: never exceeded by the many-term sums of d >= 24, exceeded at d = 1 by a fuzz case in round 3.)  The hi + lo
+// split of the time coordinate: x0 = hi + lo exactly, lo is stored rounded (<= 2^-8 |lo| <= 2^-16 x0) and the lo * lo'
+// term is dropped (<= 2^-16 x0 y0): <= 3 * 2^-16 * x0 * y0 <= 4.7e-5 * rmax2 (x0^2 <= rmax2).
 __device__ __forceinline__ float hm_scan_delta(bool bf, int kterms, const uint32_t* rmax2_bits)
 {
     const float rmax2 = hm::bitsf(rmax2_bits[0]);
     float delta = ((float)(kterms + 8) * 1.1920929e-07f) * rmax2 * 1.0001f;
-    if (bf) delta += 0.00392f * hm::bitsf(rmax2_bits[1]) + 3.1e-5f * rmax2;
+    if (bf) delta += 0.00782f * hm::bitsf(rmax2_bits[1]) + 4.7e-5f * rmax2;
     return delta;
 }
 

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             best_bits = (uint32_t)(gk >> 32);
             best_low = (uint32_t)gk;
             if (best_bits != 0xffffffffu) {
-                const float bb = hm::bitsf(best_bits + HM_TIE_SLACK) + 2.0f * delta;
+                const float bb = hm::bitsf(best_bits + hm_tie_slack(best_bits)) + 2.0f * delta;
                 if (bb < bound_f) bound_f = bb;
             }
         }
@@ -688,7 +688,7 @@ static hipError_t hm_launch_scan_ng(hm_engine* e, int sign, int mode, const Scan
     return hm_launch_scan_t<NG, 0, HM_MODE_HIST, BF, TM, WPB, SUB>(e, a, grid, s, ev0, ev1);
 }
 
-// Which prefilter form a scan uses.  The bf16 form's error bound 0.00392 * max||x_s||^2 only costs
+// Which prefilter form a scan uses.  The bf16 form's error bound 0.00782 * max||x_s||^2 only costs
 // extra emissions, never correctness; auto picks it from d >= 24 (below that the fp32 form is already short).
 bool hm_use_bf16(const hm_engine* e)
 {

@@ -222,7 +222,7 @@ int hm_launch_seed_init(hm_engine* e, const ScanArgs& a, hipStream_t s)
 // entries {bits(u_f'), i, j, sure} -> {dbits | 0xffffffff, i, j, bits(u_c')} with the canonical distance.
 // counts[0] valid, counts[1] valid & !sure, counts[3] sure & !valid (margin violated: must be 0),
 // counts[4] valid entries of the COMPLETE region -- the part of the pair space of which every pair was emitted:
-//   without a row cut: u_c' <= 1 (distance 0) or bits(u_c') + HM_TIE_SLACK <= cut_bits (a pair with u_c' <= cut
+//   without a row cut: u_c' <= 1 (distance 0) or bits(u_c') + hm_tie_slack(cut_bits) <= cut_bits (a pair with u_c' <= cut
 //   has u_f' <= cut + delta and was emitted; the slack covers the few-ulp wiggle of acosh);
 //   with a row cut (tie flood): the zero-distance pairs of rows i <= tie_imax.
 __global__ __launch_bounds__(256) void hm_post_distance_kernel(uint4* __restrict__ ent, const unsigned long long* __restrict__ ctr64,
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void hm_post_distance_kernel(uint4* __restrict
             const uint32_t ub = hm::fbits(uc);
             const bool zero = ub <= 0x3f800000u;
             const bool complete = tie_imax != 0x7fffffff ? (zero && (int)en.y <= tie_imax)
-                                                         : (zero || (cut_bits != 0xffffffffu ? (ub + HM_TIE_SLACK <= cut_bits) : true));
+                                                         : (zero || (cut_bits != 0xffffffffu ? (ub + hm_tie_slack(cut_bits) <= cut_bits) : true));
             nc += (valid && complete) ? 1u : 0u;
             ent[mine] = make_uint4(valid ? hm::fbits(dd) : 0xffffffffu, en.y, en.z, ub);
         }
@@ -616,13 +616,18 @@ static int hm_topk_core_form(hm_engine* e, float c, float thr, int64_t k, int64_
         tie_imax = -1;
     } else if (!list_all) {
         if (whole && e->have_cut && e->last_cut_k >= k && e->last_cut_c == c && e->last_cut_bits > 0x3f800000u) {
-            cut_bits = e->debug_cut ? e->last_cut_bits : e->last_cut_bits + HM_TIE_SLACK;
+            cut_bits = e->debug_cut ? e->last_cut_bits : e->last_cut_bits + hm_tie_slack(e->last_cut_bits);
             e->debug_cut = false;
         } else {
             int rc = hm_estimate_cut(e, a, grid, 4 * k + 4096, &cut_bits, &tie_imax, s);
             if (rc) return rc;
         }
     }
+    // bracket of the emission cut (bit patterns of u'): the largest cut found too tight (fewer than `want` entries in its
+    // complete region) and the smallest found too generous (emission buffer overflow).  In high dimensions the distances
+    // are so concentrated that P(u - 1 < x) grows like x^(d/2): widening a tight cut geometrically overshoots by orders of
+    // magnitude and a fresh estimate undershoots again -- once both sides are known the cut is bisected between them.
+    uint32_t tight_bits = 0u, loose_bits = 0xffffffffu;
     for (int attempt = 0; attempt < 40; ++attempt) {
         a.cut_bits = cut_bits;
         a.tie_imax = tie_imax;
@@ -652,6 +657,15 @@ static int hm_topk_core_form(hm_engine* e, float c, float thr, int64_t k, int64_
         const bool emitted_all = (cut_bits == 0xffffffffu && tie_imax == 0x7fffffff);
         if (overflow) {
             if (list_all) return hm_fail(e, HM_E_CAPACITY, "candidate listing: more candidates than the emission buffer holds");
+            if (tie_imax == 0x7fffffff && tight_bits != 0u) {
+                if (cut_bits < loose_bits) loose_bits = cut_bits;
+                // (a bracket that cannot be split: the shell of undecided pairs around the cut alone overflows the buffer --
+                // the caller retries with the fp32 prefilter, whose shell is ~100x thinner)
+                if (loose_bits <= tight_bits + 1u) return hm_fail(e, HM_E_CAPACITY, "top-k: could not bound the emission");
+                cut_bits = tight_bits + (loose_bits - tight_bits) / 2u;
+                continue;
+            }
+            if (tie_imax == 0x7fffffff && cut_bits < loose_bits) loose_bits = cut_bits;
             // estimate was too generous (or none was made): estimate with a smaller target
             int rc = hm_estimate_cut(e, a, grid, std::max<int64_t>((2 * k + 1024) >> std::min(attempt, 20), k + 64), &cut_bits, &tie_imax, s);
             if (rc) return rc;
@@ -668,9 +682,15 @@ static int hm_topk_core_form(hm_engine* e, float c, float thr, int64_t k, int64_
                 tie_imax = tie_imax >= a.row_end ? 0x7fffffff : (int)std::min<int64_t>((int64_t)tie_imax * 4 + 256, a.row_end);
                 if (tie_imax >= a.row_end) tie_imax = 0x7fffffff;
             } else {
+                if (cut_bits > tight_bits) tight_bits = cut_bits;
                 const uint32_t span = cut_bits - 0x3f800000u;
-                const uint64_t nb = (uint64_t)cut_bits + std::max<uint32_t>(span, 4u * HM_TIE_SLACK);
-                cut_bits = nb >= 0x7f800000ull ? 0xffffffffu : (uint32_t)nb;
+                const uint64_t nb = (uint64_t)cut_bits + std::max<uint32_t>(span, 4u * hm_tie_slack(cut_bits));
+                if (loose_bits != 0xffffffffu && nb >= (uint64_t)loose_bits) {
+                    if (loose_bits <= tight_bits + 1u) return hm_fail(e, HM_E_CAPACITY, "top-k: could not bound the emission");
+                    cut_bits = tight_bits + (loose_bits - tight_bits) / 2u;
+                } else {
+                    cut_bits = nb >= 0x7f800000ull ? 0xffffffffu : (uint32_t)nb;
+                }
             }
             continue;
         }
@@ -838,7 +858,7 @@ static int hm_topk_incremental_enqueue(hm_engine* e, float c, float thr, int64_t
         ScanArgs a; dim3 grid;
         if (!hm_prepare_scan(e, b, 0, -1, a, grid, -1, e->prev_n)) return hm_fail(e, HM_E_STATE, "incremental refresh: empty scan");
         a.count_sure = 0;
-        a.cut_bits = e->last_cut_bits + HM_TIE_SLACK;
+        a.cut_bits = e->last_cut_bits + hm_tie_slack(e->last_cut_bits);
         a.tie_imax = 0x7fffffff;
         HM_HIP(hm_launch_scan(e, HM_MODE_TOPK, a, grid, s));
         hipLaunchKernelGGL(hm_post_distance_kernel, dim3(256), dim3(256), 0, s, e->ent, e->d_ctr64, e->ent_cap, e->img, e->RS, e->d,

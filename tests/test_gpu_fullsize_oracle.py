@@ -70,3 +70,91 @@ def test_twenty_loop_steps_at_benchmark_size_equal_the_oracle_loop(oracle, prefi
         cur += 1
     got = tok.embeddings.data[V:cur].cpu().numpy()
     assert np.array_equal(got.view(np.uint32), Xo[V:cur].view(np.uint32))
+
+
+def test_config5_at_benchmark_size_equals_the_oracle_engine(oracle):
+    """BASELINE configs[4] as benched (`legs.config5_enhanced`: EnhancedFastHyperbolicTokenizer, V = 100 000, d = 100,
+    frequency-aware scoring + adaptive curvature) against the SAME host class driven by the oracle's engine double
+    (tests/helpers.py OracleEngine: top-k search, coherence distances, curvature-loss distances and the whole-table
+    re-projection all from oracle/): same candidates with the same scores, same merges into the same rows bit for bit, same
+    curvature after the curvature step, same generator states.  The refresh scores every candidate (919 here)."""
+    import random
+    from helpers import OracleEngine
+    from hyptokenizer_amd.engine import MergeEngine
+    from hyptokenizer_amd.tokenizer.enhanced_fast_hyperbolic_merge import EnhancedFastHyperbolicTokenizer
+    V, d, thr, steps = 100000, 100, 0.4636, 7
+    X = lorentz_table(V, d, seed=42, scale=0.05)
+    vocab = cjk_vocab(V)
+    rs = np.random.RandomState(42)
+    a, b = rs.randint(0, V, 200000), rs.randint(0, V, 200000)
+    cnt = rs.zipf(1.2, 200000).clip(max=10 ** 6)
+    freq = {(vocab[i], vocab[j]): int(c) for i, j, c in zip(a.tolist(), b.tolist(), cnt.tolist())}
+    rows = V + steps + 64
+    runs = []
+    for kind in ("hip", "oracle"):
+        random.seed(42)
+        torch.manual_seed(42)
+        dev = torch.device("cuda" if kind == "hip" else "cpu")
+        eng = MergeEngine(rows, d + 1, "lorentz", dev) if kind == "hip" else OracleEngine(rows, d + 1, "lorentz", fast=True)
+        tok = EnhancedFastHyperbolicTokenizer(vocab, torch.nn.Parameter(X.clone()), curvature=1.0, merge_threshold=thr, device=dev,
+                                              max_vocab_size=rows, sign_convention="lorentz", use_frequency_aware=True,
+                                              use_hierarchical=False, use_adaptive_curvature=True, use_compression_aware=False,
+                                              optimize_curvature_freq=3, engine=eng)
+        tok.pair_frequencies = freq
+        scored, inner = [], tok._score_candidates
+
+        def recording(dd, ii, jj, _inner=inner, _scored=scored):
+            out = _inner(dd, ii, jj)
+            _scored.extend((c.token_i, c.token_j, float(c.distance).hex(), float(c.semantic_score).hex(), float(c.combined_score).hex()) for c in out)
+            return out
+        tok._score_candidates = recording
+        tok.optimize_merges(steps=steps, log_every=10 ** 9, adaptive_threshold=False)
+        runs.append(dict(
+            scored=scored,
+            merges=[list(m) for m in tok.merge_history],
+            rows=tok.embeddings.data[V:tok.current_vocab_size].cpu().numpy().view(np.uint32).copy(),
+            curvature=float(torch.as_tensor(tok.get_curvature()).detach()),
+            cache=[(c.token_i, c.token_j, float(c.distance), float(getattr(c, 'combined_score', 0.0)), float(getattr(c, 'semantic_score', 0.0)))
+                   for c in list(tok.cache.candidates)],
+            col0=tok.embeddings.data[:V:997, 0].cpu().numpy().view(np.uint32).copy(),       # the re-projected time column, sampled
+            states=(repr(random.getstate()), torch.get_rng_state().numpy().tobytes())))
+    hip, ora = runs
+    assert len(hip["merges"]) == steps and hip["merges"] == ora["merges"]
+    assert np.array_equal(hip["rows"], ora["rows"])
+    assert hip["curvature"] == ora["curvature"] and hip["curvature"] != 1.0
+    assert np.array_equal(hip["col0"], ora["col0"])
+    assert len(hip["cache"]) > 100 and repr(hip["cache"]) == repr(ora["cache"])
+    # every candidate that was scored (919 at the refresh + 100 per step): same pair, distance, coherence and combined score
+    assert len(hip["scored"]) >= 919 and hip["scored"] == ora["scored"]
+    assert hip["states"] == ora["states"]
+
+
+@pytest.mark.parametrize("n,d,scale,seed,dup,q,f,form", [
+    (17842, 128, 0.01, 221827902, False, 1.0, 1.5, "bf16"),      # threshold above every distance: 159 M candidates within 1e-2 of u = 1
+    (27883, 100, 0.01, 730370198, True, 0.2, 1.5, "bf16"),       # the same with exact duplicates
+    (27102, 5, 0.01, 313578432, False, 0.01, 1.5, "bf16"),       # few dimensions, bf16 prefilter forced
+    (843, 1, 0.2, 192548318, False, 0.001, 1.0, "bf16"),         # d = 1: the case that exceeded the one-operand bf16 margin
+])
+def test_very_dense_tables_from_the_fuzz_runs(oracle, n, d, scale, seed, dup, q, f, form):
+    """Round-3 fuzz findings kept as tests (tools/fuzz_loops.py, tools/fuzz_parity.py): tables whose distances are so
+    concentrated that the nearest-pair search overflows its emission buffer in both prefilter forms and ends in the exact
+    top-1 search -- whose emission cut then has to be bisected (a geometric widening overshoots: P(u - 1 < x) ~ x^(d/2)) --
+    and the d = 1 table on which the bf16 margin has to cover the rounding of BOTH operands of a product."""
+    from hyptokenizer_amd.engine import MergeEngine
+    X = lorentz_table(n, d, seed=seed, scale=scale)
+    if dup:
+        X[[5, 77, 1234]] = X[[9000, 78, 20000]]
+    Xn = X.numpy()
+    m = min(n, 300)
+    D = oracle.batch_distance(Xn[:m], Xn[:m], 1.0, 1)[np.triu_indices(m, 1)]
+    thr = float(np.quantile(D[np.isfinite(D)], q)) * f
+    table = torch.zeros((n + 4, d + 1), device="cuda")
+    table[:n] = X.cuda()
+    eng = MergeEngine(n + 4, d + 1, "lorentz", prefilter=form)
+    eng.set_table(table, n)
+    od, oi, oj, oc = oracle.pairwise_topk(Xn, n, 1.0, thr, 1, 7, fast=True)
+    for rep in range(2):
+        a = eng.argmin(1.0, thr)
+        assert a is not None and (a[1], a[2]) == (int(oi[0]), int(oj[0])) and bits([a[0]])[0] == bits(od)[0], (rep, a)
+        dd, ii, jj, cnt = eng.topk(1.0, thr, 7)
+        assert cnt == oc and np.array_equal(ii, oi) and np.array_equal(jj, oj) and np.array_equal(bits(dd), bits(od)), rep
