@@ -181,6 +181,9 @@ struct hm_engine {
     int32_t* d_len = nullptr;              // token lengths (device-resident loops), max_rows entries
     bool have_len = false;
     float topk_f32_thr = 0.0f;
+    bool force_exact = false;                   // knob exact_search
+    float topk_exact_thr = 0.0f;                // > 0: whole searches at thresholds >= this one go straight to the exact path (hm_exact.hip)
+    uint32_t* d_rowcnt = nullptr;               // hm_exact.hip: per-row counts (allocated on first use)
     bool force_f32 = false;
     bool armed = false;
     int64_t armed_rb = 0, armed_re = 0;
@@ -530,5 +533,7 @@ __device__ __forceinline__ uint32_t hm_wave_incl_scan(uint32_t v, int lane)
 // ---- hm_search.hip (host) ----
 int hm_select_sorted(hm_engine* e, uint4* src, uint4* other, uint32_t m, uint32_t k, hipStream_t s);
 void hm_partition_rows(int64_t n, int world, int rank, int64_t* r0, int64_t* r1);      // hm_comm.hip
+int hm_topk_exact(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, int64_t n_limit,
+                  int64_t* n_valid_emitted, int64_t* count, uint4** result_dev, hipStream_t s);      // hm_exact.hip
 int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end, bool list_all, bool want_count,
                  int64_t n_limit, int64_t* n_valid_emitted, int64_t* count, uint4** result_dev, hipStream_t s);

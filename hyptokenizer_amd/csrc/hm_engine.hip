@@ -59,6 +59,7 @@ static int hm_apply_knob(hm_engine* e, const char* name, double v)
     else if (k == "ph_div1" || k == "ph_div2" || k == "ph_div3") { if (!(v >= 1 && v <= 64)) return HM_E_ARG; e->ph_div[k[6] - '0'] = (int)v; }
     else if (k == "pipeline") e->pipeline = v != 0.0;       // standard loop: the step's tail work under the next step's scan (0: strictly sequential)
     else if (k == "pipe_fault_at") e->pipe_fault_at = (int)v;
+    else if (k == "exact_search") e->force_exact = v != 0.0;      // every top-k / count through the prefilter-free path (hm_exact.hip): tests
     else if (k == "pipeline_pairs") { if (!(v >= 0)) return HM_E_ARG; e->pipeline_min_pairs = (int64_t)v; }
     else if (k == "kc_even") {            // bf16 image with an even chunk count (whole k-steps only): default knob only, before the images exist
         if (e->img16 != nullptr) return HM_E_STATE;
@@ -208,7 +209,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     (void)hipSetDevice(e->device);
     (void)hm_comm_destroy(e);
     void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2_mem, e->d_parts,
-                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch, e->d_rowkey};
+                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch, e->d_rowkey, e->d_rowcnt};
     for (void* q : dev_ptrs)
         if (q) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);
@@ -235,7 +236,7 @@ extern "C" int hm_set_prefilter(hm_engine* e, int prefilter)
     e->precision = prefilter;
     e->armed = false;                    // the seed's margin belongs to the form that wrote it: start the next search afresh
     e->have_cut = false;
-    e->topk_f32_thr = 0.0f;
+    e->topk_f32_thr = 0.0f; e->topk_exact_thr = 0.0f;
     return HM_OK;
 }
 
@@ -258,7 +259,7 @@ extern "C" int hm_set_table(hm_engine* e, const float* X_dev, int64_t ld, int64_
     if (rc) return rc;
     e->n = n_rows;
     e->have_cut = false;
-    e->topk_f32_thr = 0.0f;
+    e->topk_f32_thr = 0.0f; e->topk_exact_thr = 0.0f;
     HM_HIP(hipMemsetAsync(e->d_seed, 0, sizeof(ArgminSeed), s));      // new table: no seed
     return HM_OK;
 }

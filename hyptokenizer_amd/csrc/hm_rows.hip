@@ -611,7 +611,7 @@ extern "C" int hm_project_table(hm_engine* e, float* X_dev, int64_t ld, int64_t 
     e->d_rmax2 = fresh;
     e->armed = false;
     e->have_cut = false;
-    e->topk_f32_thr = 0.0f;
+    e->topk_f32_thr = 0.0f; e->topk_exact_thr = 0.0f;
     return HM_OK;
 }
 

@@ -581,13 +581,20 @@ int hm_topk_core(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin,
 {
     const bool had_bf16 = hm_use_bf16(e);
     int rc = HM_E_CAPACITY;
-    if (!(had_bf16 && e->topk_f32_thr > 0.0f && thr >= e->topk_f32_thr))     // (a fallback is remembered per table)
+    const bool exact_known = !list_all && (e->force_exact || (e->topk_exact_thr > 0.0f && thr >= e->topk_exact_thr));      // (remembered per table, like the fp32 fallback)
+    if (!exact_known && !(had_bf16 && e->topk_f32_thr > 0.0f && thr >= e->topk_f32_thr))
         rc = hm_topk_core_form(e, c, thr, k, row_begin, row_end, list_all, want_count, n_limit, n_valid_emitted, count, result_dev, s);
-    if (rc == HM_E_CAPACITY && had_bf16) {
+    if (!exact_known && rc == HM_E_CAPACITY && had_bf16 && !e->force_f32) {
         e->force_f32 = true;
         rc = hm_topk_core_form(e, c, thr, k, row_begin, row_end, list_all, want_count, n_limit, n_valid_emitted, count, result_dev, s);
         e->force_f32 = false;
         if (rc == HM_OK && !(e->topk_f32_thr > 0.0f && e->topk_f32_thr <= thr)) e->topk_f32_thr = thr;
+    }
+    if (rc == HM_E_CAPACITY && !list_all) {
+        // No emission cut fits the buffer in either prefilter form (a table whose distances sit within a few hundred ulps of
+        // u = 1): every pair evaluated exactly, selection by counting (hm_exact.hip).  Slow, and always an answer.
+        rc = hm_topk_exact(e, c, thr, k, row_begin, row_end, n_limit, n_valid_emitted, count, result_dev, s);
+        if (rc == HM_OK && !(e->topk_exact_thr > 0.0f && e->topk_exact_thr <= thr)) e->topk_exact_thr = thr;
     }
     return rc;
 }
@@ -773,6 +780,14 @@ extern "C" int hm_pairwise_argmin(hm_engine* e, float c, float thr, int64_t row_
     const bool skip_init = e->armed && e->armed_rb == req_rb && e->armed_re == req_re;
     e->armed = false;
     if (b.none || e->n < 2 || !hm_prepare_scan(e, b, row_begin, row_end, a, grid)) return HM_OK;
+    if (e->force_exact || (e->topk_exact_thr > 0.0f && thr >= e->topk_exact_thr)) {
+        // this table's searches are known to end in the prefilter-free path (hm_exact.hip): no scan attempts first
+        float d1 = 0.f; int32_t i1 = -1, j1 = -1; int64_t n1 = 0, cnt1 = 0;
+        const int rc2 = hm_pairwise_topk_nocount(e, c, thr, 1, row_begin, row_end, &d1, &i1, &j1, &n1, &cnt1, stream);
+        if (rc2) return rc2;
+        if (n1 > 0) { *found = 1; *d = d1; *i = i1; *j = j1; }
+        return HM_OK;
+    }
     const float sqrt_c = sqrtf(c);
     const int arm_re = req_re < 0 ? 0x7fffffff : (int)std::min<int64_t>(req_re, 0x7fffffff);
     for (int pass = 0; pass < 2; ++pass) {

@@ -158,3 +158,66 @@ def test_very_dense_tables_from_the_fuzz_runs(oracle, n, d, scale, seed, dup, q,
         assert a is not None and (a[1], a[2]) == (int(oi[0]), int(oj[0])) and bits([a[0]])[0] == bits(od)[0], (rep, a)
         dd, ii, jj, cnt = eng.topk(1.0, thr, 7)
         assert cnt == oc and np.array_equal(ii, oi) and np.array_equal(jj, oj) and np.array_equal(bits(dd), bits(od)), rep
+
+
+@pytest.mark.parametrize("n,d,scale,c,q,f,k,r0,r1,form", [
+    (24218, 100, 0.001, 0.3, 0.2, 1.0, 7, 14162, 21884, "bf16"),     # fuzz: every u within ~1000 ulps of 1; a row range
+    (19654, 5, 0.001, 1.0, 0.2, 1.5, 7, 6849, 9601, "bf16"),        # fuzz: ~10^6 pairs per ulp of u
+    (17453, 128, 0.001, 4.0, 0.01, 1.0, 7, 0, -1, "f32"),
+    (14391, 2, 0.001, 1.0, 0.6, 1.0, 1000, 0, -1, "bf16"),
+])
+def test_tables_no_prefilter_can_separate_take_the_exact_path(oracle, n, d, scale, c, q, f, k, r0, r1, form):
+    """Embeddings of scale 1e-3: all pairwise u lie within a few hundred ulps of 1 (up to ~10^6 pairs per ulp), the prefilter's
+    margin alone spans tens of ulps, so NO emission cut fits the buffer.  The reference evaluates every pair, and so does the
+    engine's last resort (hm_exact.hip): nearest pair, ordered top-k and the exact count equal the oracle's."""
+    from hyptokenizer_amd.engine import MergeEngine
+    X = lorentz_table(n, d, seed=n + d, scale=scale)
+    Xn = X.numpy()
+    m = min(n, 300)
+    D = oracle.batch_distance(Xn[:m], Xn[:m], c, 1)[np.triu_indices(m, 1)]
+    thr = float(np.quantile(D[np.isfinite(D)], q)) * f
+    table = torch.zeros((n + 4, d + 1), device="cuda")
+    table[:n] = X.cuda()
+    eng = MergeEngine(n + 4, d + 1, "lorentz", prefilter=form)
+    eng.set_table(table, n)
+    rr1 = n if r1 < 0 else r1
+    od, oi, oj, oc = oracle.pairwise_topk(Xn, n, c, thr, 1, k, r0, rr1, fast=True)
+    assert oc > 100000
+    for rep in range(2):                                       # (the second round goes straight to the exact path: remembered per table)
+        dd, ii, jj, cnt = eng.topk(c, thr, k, r0, r1)
+        assert cnt == oc and np.array_equal(ii, oi) and np.array_equal(jj, oj) and np.array_equal(bits(dd), bits(od)), rep
+        a = eng.argmin(c, thr, r0, r1)
+        assert a is not None and (a[1], a[2]) == (int(oi[0]), int(oj[0])) and bits([a[0]])[0] == bits(od)[0], rep
+
+
+@pytest.mark.parametrize("mode,n,d", [("lorentz", 3000, 40), ("lorentz", 700, 5), ("reference", 6500, 16), ("lorentz", 130, 127)])
+def test_exact_path_forced_on_ordinary_tables(oracle, mode, n, d):
+    """knob exact_search: the prefilter-free path on tables the two-stage search handles too -- same lists, counts, row ranges;
+    literal sign mode at n = 6 500: 21 M pairs tied at distance 0 (more than the emission buffer: the per-row count decides
+    how many rows of the tie are needed)."""
+    from hyptokenizer_amd import _lib
+    from hyptokenizer_amd.engine import MergeEngine
+    L = _lib.load()
+    X = lorentz_table(n, d, seed=11, scale=0.07)
+    X[17] = X[5]
+    Xn = X.numpy()
+    sm = 1 if mode == "lorentz" else 0
+    table = torch.zeros((n + 4, d + 1), device="cuda")
+    table[:n] = X.cuda()
+    eng = MergeEngine(n + 4, d + 1, mode)
+    _lib.check(L.hm_debug_set_knob(eng._h, b"exact_search", 1.0))
+    eng.set_table(table, n)
+    ref = MergeEngine(n + 4, d + 1, mode)
+    ref.set_table(table, n)
+    s = ref.pair_distance(np.arange(0, n // 2), np.arange(n // 2, 2 * (n // 2)), 1.0)
+    thrs = [0.1] if mode == "reference" else [float(np.percentile(s, 5)), float(np.percentile(s, 60)), 1e9]
+    for thr in thrs:
+        for k, r0, r1 in [(1, 0, -1), (300, 0, -1), (10000, 0, -1), (50, n // 3, n // 3 + 200), (0, 0, -1)]:
+            od, oi, oj, oc = oracle.pairwise_topk(Xn, n, 1.0, thr, sm, max(k, 1), r0, n if r1 < 0 else r1, fast=n > 300)
+            gd, gi, gj, gc = eng.topk(1.0, thr, k, r0, r1)
+            assert gc == oc, (thr, k, r0, gc, oc)
+            if k > 0:
+                assert np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(bits(gd), bits(od)), (thr, k, r0)
+            rd, ri, rj, rc = ref.topk(1.0, thr, k, r0, r1)
+            assert rc == gc and np.array_equal(ri, gi) and np.array_equal(rj, gj) and np.array_equal(bits(rd), bits(gd))
+        assert eng.count_candidates(1.0, thr) == ref.count_candidates(1.0, thr)

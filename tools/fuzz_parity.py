@@ -10,8 +10,8 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad = 0
 for t in range(cases):
-    n = int(rng.integers(2, 3500)); d = int(rng.choice([1, 2, 3, 5, 8, 10, 16, 23, 24, 31, 50, 64, 77, 100, 112, 124, 125, 128]))
-    scale = float(rng.choice([0.01, 0.05, 0.05, 0.2, 1.0])); mode = str(rng.choice(["lorentz", "lorentz", "reference"]))
+    n = int(rng.integers(3500, 30000)) if rng.random() < 0.12 else int(rng.integers(2, 3500)); d = int(rng.choice([1, 2, 3, 5, 8, 10, 16, 23, 24, 31, 50, 64, 77, 100, 112, 124, 125, 128]))
+    scale = float(rng.choice([0.001, 0.01, 0.05, 0.05, 0.2, 1.0])); mode = str(rng.choice(["lorentz", "lorentz", "reference"]))
     form = str(rng.choice(["f32", "bf16", "bf16-512", "bf16-k112", "bf16-512-k112"])); c = float(rng.choice([1.0, 1.0, 0.3, 4.0]))
     os.environ["HM_SCAN_PRECISION"] = form.split("-")[0]
     from hyptokenizer_amd import _lib
@@ -30,7 +30,7 @@ for t in range(cases):
     D = D[np.isfinite(D)]
     thr = float(np.quantile(D, rng.choice([0.001, 0.01, 0.2, 0.6, 1.0]))) * float(rng.choice([1.0, 1.0, 1.5])) if len(D) else 0.1
     if mode == "reference": thr = 0.1
-    k = int(rng.choice([1, 7, 100, 1000]))
+    k = int(rng.choice([1, 7, 100, 1000, 10000]))
     if rng.random() < 0.4 and n > 4:
         r0 = int(rng.integers(0, n - 1)); r1 = int(rng.integers(r0 + 1, n + 1))
     else:
