@@ -635,6 +635,7 @@ static int hm_topk_core_form(hm_engine* e, float c, float thr, int64_t k, int64_
     // are so concentrated that P(u - 1 < x) grows like x^(d/2): widening a tight cut geometrically overshoots by orders of
     // magnitude and a fresh estimate undershoots again -- once both sides are known the cut is bisected between them.
     uint32_t tight_bits = 0u, loose_bits = 0xffffffffu;
+    int stuck = 0;
     for (int attempt = 0; attempt < 40; ++attempt) {
         a.cut_bits = cut_bits;
         a.tie_imax = tie_imax;
@@ -674,9 +675,14 @@ static int hm_topk_core_form(hm_engine* e, float c, float thr, int64_t k, int64_
             }
             if (tie_imax == 0x7fffffff && cut_bits < loose_bits) loose_bits = cut_bits;
             // estimate was too generous (or none was made): estimate with a smaller target
-            int rc = hm_estimate_cut(e, a, grid, std::max<int64_t>((2 * k + 1024) >> std::min(attempt, 20), k + 64), &cut_bits, &tie_imax, s);
+            const int64_t target = std::max<int64_t>((2 * k + 1024) >> std::min(attempt, 20), k + 64);
+            int rc = hm_estimate_cut(e, a, grid, target, &cut_bits, &tie_imax, s);
             if (rc) return rc;
             if (cut_bits == 0xffffffffu) return hm_fail(e, HM_E_CAPACITY, "top-k: could not bound the emission");
+            // the smallest target already, and its cut is one that is known to overflow: estimating again would give the same
+            // cut (a table too dense for any cut of this prefilter form -- the caller moves on to the next form / the exact path)
+            if (tie_imax == 0x7fffffff && target == k + 64 && cut_bits >= loose_bits && ++stuck >= 2)
+                return hm_fail(e, HM_E_CAPACITY, "top-k: could not bound the emission");
             continue;
         }
         // exact total (when counted): sure + valid borderline; everything emitted: the valid ones

@@ -98,7 +98,11 @@ int hm_pairwise_argmin_dev(hm_engine* e, float c, float thr, int64_t row_begin, 
 /* K2: the k smallest candidates in order, and the exact number of candidates.
  * d_out/i_out/j_out have room for k entries (may be NULL when k == 0); *n_out = min(k, *count).
  * Replaces: the recompute branch of _find_merge_candidates_fast + candidates.sort() +
- * AdaptiveMergeCache.add_batch truncation to max_size (fast_hyperbolic_merge.py:336-355,371-374,78-95). */
+ * AdaptiveMergeCache.add_batch truncation to max_size (fast_hyperbolic_merge.py:336-355,371-374,78-95).
+ * Always answers for k <= 65536: a table whose distances are so concentrated that no emission cut of the matrix-core
+ * prefilter fits the engine's buffers (all u within a few hundred ulps of 1) is searched by evaluating every pair in the
+ * canonical arithmetic and selecting by counting (hm_exact.hip) -- like the reference, only slower than the usual path
+ * (56 ms at 25 000 rows).  The same holds for hm_pairwise_argmin, hm_pairwise_topk_nocount and hm_pairwise_count. */
 int hm_pairwise_topk(hm_engine* e, float c, float thr, int64_t k, int64_t row_begin, int64_t row_end,
                      float* d_out, int32_t* i_out, int32_t* j_out, int64_t* n_out, int64_t* count,
                      void* stream);
