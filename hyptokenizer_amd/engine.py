@@ -49,6 +49,15 @@ def _f(x) -> float:
     return float(x.detach()) if isinstance(x, torch.Tensor) else float(x)
 
 
+def _nan_c(c) -> bool:
+    """A NaN curvature -- what the enhanced tokenizer's Adam step leaves behind once a NaN row (merge of identical rows, SURVEY
+    F6) is sampled into its loss: the reference then computes on silently, every distance is NaN (``acosh(u) / sqrt(nan)``), no
+    pair is below any threshold and ``project_to_hyperboloid`` writes NaN time coordinates.  The C ABI rejects a curvature that
+    is not > 0, so the host mirror answers these calls itself, with exactly those values."""
+    v = _f(c)
+    return v != v
+
+
 class MergeEngine:
     """Handle of one ``hm_engine`` (include/hypmerge.h)."""
 
@@ -118,6 +127,8 @@ class MergeEngine:
     # ------------------------------------------------------------------------------------------
     def argmin(self, c: float, thr: float, row_begin: int = 0, row_end: int = -1) -> Optional[Tuple[float, int, int]]:
         """Nearest pair (d, i, j) with d < thr in the reference's order, or None."""
+        if _nan_c(c):
+            return None
         d, i, j, f = C.c_float(0), C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
         self._chk(self._L.hm_pairwise_argmin(self._h, _f(c), float(thr), int(row_begin), int(row_end),
                                              C.byref(d), C.byref(i), C.byref(j), C.byref(f), self._stream()))
@@ -127,6 +138,8 @@ class MergeEngine:
 
     def row_argmin(self, row: int, n_partners: int, c: float, thr: float) -> Optional[Tuple[float, int, int]]:
         """Nearest partner of `row` among rows [0, n_partners): (d, i, j) with i < j, or None."""
+        if _nan_c(c):
+            return None
         d, i, j, f = C.c_float(0), C.c_int32(-1), C.c_int32(-1), C.c_int32(0)
         self._chk(self._L.hm_row_argmin(self._h, int(row), int(n_partners), _f(c), float(thr),
                                         C.byref(d), C.byref(i), C.byref(j), C.byref(f), self._stream()))
@@ -146,6 +159,8 @@ class MergeEngine:
         """k smallest candidates (d, i, j) in order and the exact candidate count.  ``count=False``: the
         count is -1 when at least k candidates exist (not counted: the scan then only visits what lies below
         its emission cut; ``count_candidates`` delivers the number later)."""
+        if _nan_c(c):
+            return np.empty(0, np.float32), np.empty(0, np.int32), np.empty(0, np.int32), 0
         k = int(k)
         d = np.empty(k, np.float32)
         i = np.empty(k, np.int32)
@@ -161,6 +176,8 @@ class MergeEngine:
         """Enqueue the refresh of a table that only grew since the last whole-table ``topk`` and return at once
         (``False``: not of that kind -- use ``topk``).  Nothing else may be asked of the engine until
         ``topk_refresh_end``."""
+        if _nan_c(c):
+            return False
         st = self._L.hm_topk_refresh_begin(self._h, _f(c), float(thr), int(k), self._stream())
         if st == _lib.HM_E_NA:                     # the refresh is not of the incremental kind (HM_E_STATE stays an error)
             return False
@@ -188,6 +205,8 @@ class MergeEngine:
 
     def count_candidates(self, c: float, thr: float, n_limit: int = -1) -> int:
         """Exact number of candidates among the first ``n_limit`` rows (-1: all live rows)."""
+        if _nan_c(c):
+            return 0
         total = C.c_int64(0)
         self._chk(self._L.hm_pairwise_count(self._h, _f(c), float(thr), int(n_limit), C.byref(total), self._stream()))
         return int(total.value)
@@ -201,6 +220,8 @@ class MergeEngine:
 
     def candidates(self, c: float, thr: float, row_begin: int = 0, row_end: int = -1, cap: int = 1 << 24):
         """All candidates in row-major order: (i, j, d, total)."""
+        if _nan_c(c):
+            return np.empty(0, np.int32), np.empty(0, np.int32), np.empty(0, np.float32), 0
         total = C.c_int64(0)
         # first call sizes the arrays
         self._chk(self._L.hm_pairwise_candidates(self._h, _f(c), float(thr), int(row_begin), int(row_end), 0,
@@ -224,6 +245,8 @@ class MergeEngine:
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=self.device)
 
     def pair_distance(self, I, J, c: float) -> np.ndarray:
+        if _nan_c(c):
+            return np.full(len(I), np.nan, np.float32)
         ti, tj = self._idx(I), self._idx(J)
         out = torch.empty(ti.numel(), dtype=torch.float32, device=self.device)
         self._chk(self._L.hm_pair_distance(self._h, _ptr(ti), _ptr(tj), ti.numel(), _f(c), _ptr(out), self._stream()))
@@ -378,6 +401,8 @@ class MergeEngine:
     def coherence_distances(self, I, J, W, S, c: float) -> np.ndarray:
         """distance(exp_map(x_i, w * log_map(x_i, x_j)), x_s) for every candidate t and its samples S[t, :]
         (enhanced_fast_hyperbolic_merge.py:308-333) -> float32 [b, ns]."""
+        if _nan_c(c):
+            return np.full((len(I), np.asarray(S).reshape(len(I), -1).shape[1] if len(I) else 0), np.nan, np.float32)
         ti, tj = self._idx(I), self._idx(J)
         tw = torch.as_tensor(np.ascontiguousarray(W, dtype=np.float32), device=self.device)
         S = np.ascontiguousarray(S, dtype=np.int32).reshape(ti.numel(), -1)
@@ -392,6 +417,10 @@ class MergeEngine:
         """The same launch without the wait: kernel and the copy of its result into pinned host memory are enqueued and a
         handle comes back at once -- the caller draws the NEXT batch's samples on the host meanwhile (the enhanced
         tokenizer's scoring: the host RNG is the long pole) and collects with ``coherence_distances_end``."""
+        if _nan_c(c):
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            return (torch.from_numpy(self.coherence_distances(I, J, W, S, c)), ev, None)
         ti, tj = self._idx(I), self._idx(J)
         tw = torch.as_tensor(np.ascontiguousarray(W, dtype=np.float32), device=self.device)
         S = np.ascontiguousarray(S, dtype=np.int32).reshape(ti.numel(), -1)
@@ -418,10 +447,16 @@ class MergeEngine:
         t = self._check_table(table)
         if n_rows > t.shape[0]:
             raise ValueError("n_rows outside the table")
+        if _nan_c(c):                              # sqrt(1 + nan * r^2): every time coordinate NaN; images rebuilt from the table
+            t[: int(n_rows), 0] = float("nan")
+            self.set_table(t, self.n)
+            return
         self._chk(self._L.hm_project_table(self._h, _ptr(t), t.stride(0), int(n_rows), _f(c), self._stream()))
 
     def rows_pair_distance(self, table: torch.Tensor, A, B, c: float) -> np.ndarray:
         """distance(table[A[t]], table[B[t]]) on ANY rows of the caller's table (not only live image rows)."""
+        if _nan_c(c):
+            return np.full(len(A), np.nan, np.float32)
         t = table.detach()
         ia = torch.as_tensor(np.ascontiguousarray(A, dtype=np.int64), device=t.device)
         ib = torch.as_tensor(np.ascontiguousarray(B, dtype=np.int64), device=t.device)
@@ -429,6 +464,8 @@ class MergeEngine:
         return out.cpu().numpy()
 
     def row_vs_all(self, row: int, n: int, c: float) -> np.ndarray:
+        if _nan_c(c):
+            return np.full(int(n), np.nan, np.float32)
         out = torch.empty(int(n), dtype=torch.float32, device=self.device)
         self._chk(self._L.hm_row_vs_all(self._h, int(row), int(n), _f(c), _ptr(out), self._stream()))
         return out.cpu().numpy()

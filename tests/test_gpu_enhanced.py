@@ -89,3 +89,42 @@ def test_project_table_equals_oracle_and_keeps_searches_exact(oracle, d):
             assert (a[1], a[2]) == (int(oi[0]), int(oj[0])) and bits([a[0]])[0] == bits(od)[0]
         gd, gi, gj, gc = eng.topk(c, thr2, 300)
         assert gc == oc and np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(bits(gd), bits(od))
+
+
+def test_nan_curvature_is_carried_like_the_reference_carries_it(oracle):
+    """Two identical rows merge into a NaN row; the adaptive-curvature step samples it, its loss and Adam step turn
+    the curvature into NaN (the clamp keeps NaN), and the reference computes on: NaN time coordinates after the re-projection,
+    no pair below any threshold.  The C ABI refuses a curvature that is not > 0, so the host mirror answers those calls with
+    the same values -- the run equals the oracle engine's, no exception."""
+    import random
+    from helpers import OracleEngine
+    from hyptokenizer_amd.engine import MergeEngine
+    from hyptokenizer_amd.synthetic import cjk_vocab
+    from hyptokenizer_amd.tokenizer.enhanced_fast_hyperbolic_merge import EnhancedFastHyperbolicTokenizer
+    n, d, steps = 60, 12, 9
+    X = lorentz_table(n, d, seed=4, scale=0.1)
+    X[11] = X[3]
+    vocab = cjk_vocab(n)
+    runs = []
+    for kind in ("hip", "oracle"):
+        random.seed(7)
+        torch.manual_seed(7)
+        dev = torch.device("cuda" if kind == "hip" else "cpu")
+        rows = n + steps + 8
+        eng = MergeEngine(rows, d + 1, "lorentz", dev) if kind == "hip" else OracleEngine(rows, d + 1, "lorentz", fast=False)
+        tok = EnhancedFastHyperbolicTokenizer(vocab, torch.nn.Parameter(X.clone()), merge_threshold=0.6, device=dev, max_vocab_size=rows,
+                                              sign_convention="lorentz", engine=eng, use_frequency_aware=True, use_hierarchical=False,
+                                              use_adaptive_curvature=True, use_compression_aware=False, optimize_curvature_freq=2)
+        tok.pair_frequencies = {}
+        tok.optimize_merges(steps=steps, log_every=10 ** 9, adaptive_threshold=False)
+        runs.append((tok.merge_history, repr(float(torch.as_tensor(tok.get_curvature()).detach())),
+                     tok.embeddings.data[: tok.current_vocab_size].cpu().numpy().view(np.uint32).copy(),
+                     torch.get_rng_state().numpy().tobytes()))
+        if kind == "hip":                                      # the engine-level answers under a NaN curvature
+            nan = float("nan")
+            assert eng.argmin(nan, 1.0) is None and eng.count_candidates(nan, 1.0) == 0 and eng.topk(nan, 1.0, 5)[3] == 0
+            assert np.isnan(eng.pair_distance([0, 1], [2, 3], nan)).all() and np.isnan(eng.row_vs_all(0, 5, nan)).all()
+    hip, ora = runs
+    assert hip[1] == "nan" and ora[1] == "nan"
+    assert [list(m) for m in hip[0]] == [list(m) for m in ora[0]] and len(hip[0]) >= 1
+    assert np.array_equal(hip[2], ora[2]) and hip[3] == ora[3]

@@ -19,6 +19,8 @@ for t in range(cases):
     _L.hm_debug_set_default_knob(None, 0.0, 1)
     if "512" in form: _L.hm_debug_set_default_knob(b"big_rows", 2.0, 0)
     if form.endswith("k112"): _L.hm_debug_set_default_knob(b"kc_even", 1.0, 0)
+    if rng.random() < 0.12:                               # the prefilter-free path (hm_exact.hip) on an ordinary table
+        _L.hm_debug_set_default_knob(b"exact_search", 1.0, 0); form += "+exact"
     X = lorentz_table(n, d, seed=int(rng.integers(1 << 30)), scale=scale)
     if rng.random() < 0.2 and n > 10:                     # a few exact duplicates
         X[rng.integers(n, size=3)] = X[rng.integers(n, size=3)]
@@ -73,4 +75,6 @@ for t in range(cases):
     except Exception as ex:
         bad += 1
         print("ERROR", dict(n=n, d=d, scale=scale, mode=mode, form=form, c=c, thr=thr, k=k, r0=r0, r1=r1), repr(ex)[:200], flush=True)
+    if t % 25 == 24:
+        print(f"{t + 1} cases, {bad} bad", flush=True)
 print(f"{cases} cases, {bad} bad")
