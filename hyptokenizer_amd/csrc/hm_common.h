@@ -184,6 +184,7 @@ struct hm_engine {
     bool force_exact = false;                   // knob exact_search
     float topk_exact_thr = 0.0f;                // > 0: whole searches at thresholds >= this one go straight to the exact path (hm_exact.hip)
     uint32_t* d_rowcnt = nullptr;               // hm_exact.hip: per-row counts (allocated on first use)
+    LoopState* h_loop = nullptr;                // pinned host image of a LoopState: the incremental loop's initial state goes up, and its final state comes back, in ONE copy each
     bool force_f32 = false;
     bool armed = false;
     int64_t armed_rb = 0, armed_re = 0;

@@ -215,6 +215,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     if (e->h) (void)hipHostFree(e->h);
     if (e->h_sorted) (void)hipHostFree(e->h_sorted);
     if (e->h_batch) (void)hipHostFree(e->h_batch);
+    if (e->h_loop) (void)hipHostFree(e->h_loop);
     if (e->ev_batch) (void)hipEventDestroy(e->ev_batch);
     for (int q = 0; q < 2; ++q) {
         if (e->ev_scan[q]) (void)hipEventDestroy(e->ev_scan[q]);

@@ -466,13 +466,13 @@ extern "C" int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_de
     HM_HIP(hipSetDevice(e->device));
     e->armed = false;
     const int64_t n0 = e->n;
-    LoopState st;
-    memset(&st, 0, sizeof(st));
-    st.best[0].found = best_io[0]; st.best[0].dbits = best_io[1]; st.best[0].i = best_io[2]; st.best[0].j = best_io[3];
-    memcpy(&e->h->rec2[0], &st.best[0], sizeof(ArgminRec));
-    HM_HIP(hipMemsetAsync(e->d_loop, 0, sizeof(LoopState), s));
-    HM_HIP(hipMemsetAsync(e->d_loop->rowkey, 0xff, sizeof(unsigned long long) * HM_LOOP_MAX_STEPS, s));
-    HM_HIP(hipMemcpyAsync(&e->d_loop->best[0], &e->h->rec2[0], sizeof(ArgminRec), hipMemcpyHostToDevice, s));
+    // initial state in one copy: zeros, best[0] = the caller's nearest pair, row keys of this batch's steps = "none"
+    if (!e->h_loop) HM_HIP(hipHostMalloc(&e->h_loop, sizeof(LoopState), hipHostMallocDefault));
+    const size_t state_bytes = offsetof(LoopState, rowkey) + sizeof(unsigned long long) * (size_t)steps;
+    memset(e->h_loop, 0, offsetof(LoopState, rowkey));
+    memset(e->h_loop->rowkey, 0xff, sizeof(unsigned long long) * (size_t)steps);
+    e->h_loop->best[0].found = best_io[0]; e->h_loop->best[0].dbits = best_io[1]; e->h_loop->best[0].i = best_io[2]; e->h_loop->best[0].j = best_io[3];
+    HM_HIP(hipMemcpyAsync(e->d_loop, e->h_loop, state_bytes, hipMemcpyHostToDevice, s));
     IncrArgs a;
     a.img = e->img; a.img16 = e->img16; a.RS = e->RS; a.d = e->d; a.KC = e->KC; a.sign_mode = e->sign_mode;
     a.c = c; a.sqrt_c = sqrtf(c); a.thr = thr; a.X = X_dev; a.ld = ld; a.len = e->d_len; a.loop = e->d_loop;
@@ -494,10 +494,11 @@ extern "C" int hm_incr_merge_steps(hm_engine* e, float c, float thr, float* X_de
         HM_HIP(hipGetLastError());
     }
     HM_HIP(hipMemcpyAsync(e->h->loop_recs, e->d_loop_recs, sizeof(ArgminRec) * (size_t)steps, hipMemcpyDeviceToHost, s));
-    // (the slot the last launch WROTE: step steps - 1 wrote best[steps & 1]; a launch that stopped wrote nothing -- unused then)
-    HM_HIP(hipMemcpyAsync(&e->h->rec, &e->d_loop->best[steps & 1], sizeof(ArgminRec), hipMemcpyDeviceToHost, s));
-    HM_HIP(hipMemcpyAsync(e->h->ctr64, e->d_loop->rowkey + (steps - 1), sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HM_HIP(hipMemcpyAsync(e->h_loop, e->d_loop, state_bytes, hipMemcpyDeviceToHost, s));          // final state: best[] and the last row key
     HM_HIP(hipStreamSynchronize(s));
+    // (the slot the last launch WROTE: step steps - 1 wrote best[steps & 1]; a launch that stopped wrote nothing -- unused then)
+    e->h->rec = e->h_loop->best[steps & 1];
+    e->h->ctr64[0] = e->h_loop->rowkey[steps - 1];
     hm_unpack_recs(e->h->loop_recs, steps, rec_out, done);
     // the running minimum after the last executed step: its start-of-step value folded with that step's row pass
     // (when the batch ran to its end; an earlier stop means the minimum did not exist: found = 0)
