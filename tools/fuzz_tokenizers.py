@@ -56,7 +56,7 @@ for t in range(cases):
             if which == "hip" and not cpu_only:
                 eng = MergeEngine(rows, d + 1, mode, dev)
             else:
-                eng = OracleEngine(rows, d + 1, mode, fast=(which == "hip"))
+                eng = OracleEngine(rows, d + 1, mode, fast=(which == "hip") or n > 300)       # (the OpenMP form for the larger tables: checked against the plain form in tests/)
             emb = torch.nn.Parameter(X.clone())
             if kind in ("std", "incr"):
                 tok = HyperbolicTokenizer(vocab, emb, merge_threshold=thr, device=dev, max_vocab_size=rows, sign_convention=mode,
