@@ -87,7 +87,7 @@ struct ScanArgs {
     // ph_rb0[q] + b / ph_chunks[q], tiles from ph_ctmin[q] + (b % ph_chunks[q]) * ph_ch[q]).  Chunk lengths shrink from
     // phase to phase: long items first, ever shorter ones behind them, so that the slots that free up late are filled
     // with work that still ends with the rest (the launch's tail is made of the shortest blocks).
-#define HM_SCAN_PHASES 4
+#define HM_SCAN_PHASES 6
     int n_ph;
     int ph_items[HM_SCAN_PHASES], ph_rb0[HM_SCAN_PHASES], ph_chunks[HM_SCAN_PHASES], ph_ch[HM_SCAN_PHASES], ph_ctmin[HM_SCAN_PHASES];
     float u_hi;                   // candidate prefilter: u < u_hi
@@ -112,6 +112,18 @@ struct ScanArgs {
     const uint32_t* order_seen;
     uint32_t order_need;
     uint32_t* order_fault;
+    // item queue (knob `dyn`, on by default for the bf16 form): the grid is only as large as the device holds at once; block b
+    // starts on item b and then draws further items of the SAME list, in order, from a device counter until n_items is
+    // reached -- no dispatch gap between a slot's items, and the slots of a fast XCD take work that a static grid
+    // (workgroup id mod 8 -> XCD) would have pinned to a slow one: 3 % off the launch at V = 50 k and 100 k.
+    // The word is (launch tag << 24) | next item offset: every block raises it to its launch's tag first (atomicMax), so it
+    // needs no reset between launches and a zeroed or stale word is harmless.  It lives in a cache line of its OWN
+    // (hm_engine::d_queue): on the line of ctr64[] -- whose running key every wave polls -- each draw took ~20 us
+    // (profiles/r03g_ab_item_queue_shared_line.txt: the launch 22 % slower than the static grid).
+    int dyn;
+    int n_items;
+    unsigned long long q_tag;
+    unsigned long long* q_ctr;
 };
 
 // Seed of the argmin search's running key, kept on the device between searches: the key of the last
@@ -151,13 +163,18 @@ struct hm_engine {
     int device = 0;
     int n_cu = 256;
     // work-decomposition knobs (hm_debug_set_knob; tuning builds also read HM_TUNE_<NAME>)
-    int chunk_f32 = 32, chunk_bf16 = 96, tail_div = 4;
+    int chunk_f32 = 32, chunk_bf16 = 128, tail_div = 4;   // (bf16: 96 with the static grid; 112-144 measure alike with the item queue)
     double tail_fraction = 0.20;
     // phases of the item list: work share of each phase from the top of the triangle (the last one takes the rest), chunk
     // length divisor per phase.  phases = 2 is the round-2 list: [1 - tail_fraction, tail_fraction] at [1, tail_div]
     int phases = 4;                      // (measured, interleaved A/B at V = 50 k / 100 k: +1.3 % / +2.6 % over the two-phase list)
-    double ph_share[3] = {0.70, 0.15, 0.10};
-    int ph_div[4] = {1, 2, 4, 8};
+    double ph_share[HM_SCAN_PHASES - 1] = {0.70, 0.15, 0.10, 0.0, 0.0};
+    int ph_div[HM_SCAN_PHASES] = {1, 2, 4, 8, 16, 32};
+    unsigned long long* d_queue = nullptr; // item queue words: 2 x 128 B (one per counter set), never reset (ScanArgs::q_tag)
+    int dyn_slots = 0;                    // knob `dyn_slots` (tests): resident-grid size of the item queue; 0 = what the device holds (occupancy x CUs)
+    bool dyn_queue = true;                // knob `dyn`: resident grid + in-order item queue (ScanArgs::dyn) for bf16 ARGMIN / TOPK launches
+    unsigned long long scan_tag = 0;      // launch tags of the item queue (monotonic per engine)
+    std::map<const void*, int> scan_slots; // resident blocks per scan kernel instantiation on this engine's device
     int force_shape = -1;                 // HM_TUNE_SHAPE: bf16 block shape of every launch (tuning builds)
     int64_t big_min_rows = 80000;         // bf16 form: launches covering at least the pairs of this many rows use 512-row blocks
     int64_t max_rows = 0, rows_alloc = 0, n = 0;

@@ -40,8 +40,8 @@ extern "C" int hm_abi_version(void) { return HM_ABI_VERSION; }
 
 // ---- work-decomposition knobs (test / tuning hook: hm_debug_set_knob, hm_debug_set_default_knob) ----
 #if defined(HM_TUNING)
-static const char* const kKnobNames[] = {"chunk", "tail", "tail_div", "big_rows", "shape", "incr_topk", "kc_even", "phases", "ph_share0", "ph_share1", "ph_share2",
-                                        "ph_div1", "ph_div2", "ph_div3", "pipeline", "pipe_fault_at", "pipeline_pairs"};
+static const char* const kKnobNames[] = {"chunk", "tail", "tail_div", "big_rows", "shape", "incr_topk", "kc_even", "phases", "ph_share0", "ph_share1", "ph_share2", "ph_share3", "ph_share4",
+                                        "ph_div1", "ph_div2", "ph_div3", "ph_div4", "ph_div5", "pipeline", "pipe_fault_at", "pipeline_pairs", "dyn", "dyn_slots"};
 #endif
 static std::map<std::string, double> g_default_knobs;          // applied to every engine created afterwards
 
@@ -55,8 +55,10 @@ static int hm_apply_knob(hm_engine* e, const char* name, double v)
     else if (k == "shape") { if (!(v >= -1 && v <= 4)) return HM_E_ARG; e->force_shape = (int)v; }
     else if (k == "incr_topk") e->incremental_topk = v != 0.0;
     else if (k == "phases") { if (!(v >= 1 && v <= HM_SCAN_PHASES)) return HM_E_ARG; e->phases = (int)v; }
-    else if (k == "ph_share0" || k == "ph_share1" || k == "ph_share2") { if (!(v >= 0.0 && v <= 1.0)) return HM_E_ARG; e->ph_share[k[8] - '0'] = v; }
-    else if (k == "ph_div1" || k == "ph_div2" || k == "ph_div3") { if (!(v >= 1 && v <= 64)) return HM_E_ARG; e->ph_div[k[6] - '0'] = (int)v; }
+    else if (k.size() == 9 && k.compare(0, 8, "ph_share") == 0 && k[8] >= '0' && k[8] < '0' + HM_SCAN_PHASES - 1) { if (!(v >= 0.0 && v <= 1.0)) return HM_E_ARG; e->ph_share[k[8] - '0'] = v; }
+    else if (k.size() == 7 && k.compare(0, 6, "ph_div") == 0 && k[6] >= '1' && k[6] < '0' + HM_SCAN_PHASES) { if (!(v >= 1 && v <= 64)) return HM_E_ARG; e->ph_div[k[6] - '0'] = (int)v; }
+    else if (k == "dyn_slots") { if (!(v >= 0 && v <= 65536)) return HM_E_ARG; e->dyn_slots = (int)v; }
+    else if (k == "dyn") e->dyn_queue = v != 0.0;           // scan: resident grid + in-order item queue instead of one block per item
     else if (k == "pipeline") e->pipeline = v != 0.0;       // standard loop: the step's tail work under the next step's scan (0: strictly sequential)
     else if (k == "pipe_fault_at") e->pipe_fault_at = (int)v;
     else if (k == "exact_search") e->force_exact = v != 0.0;      // every top-k / count through the prefilter-free path (hm_exact.hip): tests
@@ -120,6 +122,8 @@ static int hm_engine_alloc(hm_engine* e)
     e->d_rmax2 = e->d_rmax2_mem;
     HM_HIP(hipMalloc(&e->d_ctr64, sizeof(unsigned long long) * 8));            // two sets of 4 (the second: pipelined loop)
     HM_HIP(hipMemset(e->d_ctr64, 0, sizeof(unsigned long long) * 8));
+    HM_HIP(hipMalloc(&e->d_queue, 256));
+    HM_HIP(hipMemset(e->d_queue, 0, 256));
     HM_HIP(hipMalloc(&e->d_rowkey, sizeof(unsigned long long) * 3));
     HM_HIP(hipMemset(e->d_rowkey, 0xff, sizeof(unsigned long long) * 3));
     HM_HIP(hipMalloc(&e->d_seed, sizeof(ArgminSeed)));
@@ -209,7 +213,7 @@ extern "C" int hm_engine_destroy(hm_engine* e)
     (void)hipSetDevice(e->device);
     (void)hm_comm_destroy(e);
     void* dev_ptrs[] = {e->img, e->ent, e->ent2, e->sorted, e->d_ctr, e->d_ctr64, e->d_rec, e->d_hist, e->d_rmax2_mem, e->d_parts,
-                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch, e->d_rowkey, e->d_rowcnt};
+                        e->img16, e->d_seed, e->d_loop_recs, e->d_loop, e->d_len, e->d_prev, e->d_batch, e->d_rowkey, e->d_rowcnt, e->d_queue};
     for (void* q : dev_ptrs)
         if (q) (void)hipFree(q);
     if (e->h) (void)hipHostFree(e->h);

@@ -484,9 +484,19 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         }
     };
 
-    // ---- work distribution: static, block b owns item b of the host's list (hm_prepare_scan) ----
+    // ---- work distribution: block b owns item b of the host's list (hm_prepare_scan); with the item queue (p.dyn) the grid
+    // is the resident set and every block goes on drawing items of the same list, in order, from the queue word p.q_ctr ----
+    constexpr int QOFF = NBUF * TILE_LDS + 32 * ROW_BYTES + (MODE == HM_MODE_HIST ? (int)sizeof(uint32_t) * HM_HIST_BINS : 0);
+    volatile uint32_t* const qslot = reinterpret_cast<volatile uint32_t*>(smem + QOFF);      // the drawn counter value, for all waves
+    const bool dyn = (MODE != HM_MODE_HIST) && (p.dyn != 0);
+    unsigned long long q_raw = 0ull;     // destination of the asynchronous draw (thread 0)
+    if (dyn && threadIdx.x == 0) (void)__hip_atomic_fetch_max(p.q_ctr, p.q_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int item = (int)blockIdx.x;
+#pragma unroll 1
+    for (;;) {
+    bool have = true;                   // the item has tiles right of the diagonal
     {
-        int it = (int)blockIdx.x, ph = 0;
+        int it = item, ph = 0;
         while (ph + 1 < p.n_ph && it >= p.ph_items[ph]) { it -= p.ph_items[ph]; ++ph; }
         rb = p.ph_rb0[ph] + it / p.ph_chunks[ph];
         ct0 = p.ph_ctmin[ph] + (it % p.ph_chunks[ph]) * p.ph_ch[ph];
@@ -495,22 +505,22 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     if (ct0 < (rb * BLOCK_ROWS) / COLS) ct0 = (rb * BLOCK_ROWS) / COLS;   // left of the diagonal: no i < j
     if (ct0 < p.col_begin / COLS) ct0 = p.col_begin / COLS;               // partner rows in front of col_begin are not asked for
     if (ct1 > p.nct) ct1 = p.nct;
-    if (ct0 >= ct1) return;
+    if (ct0 >= ct1) have = false;
 
+    // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
+    int ct_step = 1;
+    if (MODE == HM_MODE_HIST && have) {
+        ct_step = p.sample_stride;
+        ct0 += (ct_step - (ct0 + rb * 7) % ct_step) % ct_step;
+        if (ct0 >= ct1) have = false;
+    }
+    if (have) {
     if (rb != rb_cur) {
         rb_cur = rb;
         i0w = rb * BLOCK_ROWS + wave * WAVE_ROWS;
         wave_active = (i0w < p.row_end) && (i0w + WAVE_ROWS - 1 >= p.row_begin) && (i0w < p.n);
         rows_full = (i0w >= p.row_begin) && (i0w + WAVE_ROWS - 1 < p.row_end);
         load_a();
-    }
-
-    // HIST mode visits every sample_stride-th tile only (a cheap estimate of the u' distribution)
-    int ct_step = 1;
-    if (MODE == HM_MODE_HIST) {
-        ct_step = p.sample_stride;
-        ct0 += (ct_step - (ct0 + rb * 7) % ct_step) % ct_step;
-        if (ct0 >= ct1) return;
     }
     const int ntile = (ct1 - ct0 + ct_step - 1) / ct_step;
     auto tile_at = [&](int t) { return ct0 + t * ct_step; };
@@ -545,6 +555,9 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
             asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(gk_raw) : "v"(&p.ctr64[1]) : "memory");
             gk_pending = true;
         }
+        // item queue: the next item is drawn during this item's last tile (picked up behind the same counted wait)
+        if (dyn && t == ntile - 1 && threadIdx.x == 0)
+            asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0" : "=v"(q_raw) : "v"(p.q_ctr), "v"(1ull) : "memory");
         dma_tile(ct_next, buf_next);
 
         if constexpr (!PIPE) {
@@ -616,12 +629,13 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
         }
 
         // tile t+1 has landed (this wave's pieces) -- and so has the key load, if one was issued
-        if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gk_raw) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gk_raw) : "n"((DIST - 1) * PPW) : "memory");
+        if (DIST - 1 <= 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gk_raw), "+v"(q_raw) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(gk_raw), "+v"(q_raw) : "n"((DIST - 1) * PPW) : "memory");
         if (MODE == HM_MODE_ARGMIN && gk_pending) {
             if (gk_raw < gk) gk = gk_raw;                   // the key only ever decreases
             gk_pending = false;
         }
+        if (dyn && t == ntile - 1 && threadIdx.x == 0) { qslot[0] = (uint32_t)q_raw; qslot[1] = (uint32_t)(q_raw >> 32); }
         __syncthreads();                                     // ... and every wave's; all reads of slot `buf` done
         if (++buf == NBUF) buf = 0;
     }
@@ -633,6 +647,27 @@ __global__ __launch_bounds__(64 * WPB, 2) void hm_scan_kernel(const ScanArgs p)
     }
 
     if (DIST > 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }   // nothing of this run may land later
+    }   // have
+
+    if (!dyn) break;
+    if (!have) {
+        // an item left of the diagonal: draw at once (the barrier in front keeps the slot's previous value readable
+        // until every wave has it)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long v = __hip_atomic_fetch_add(p.q_ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            qslot[0] = (uint32_t)v; qslot[1] = (uint32_t)(v >> 32);
+        }
+        __syncthreads();
+    }
+    {
+        const uint32_t qlo = __builtin_amdgcn_readfirstlane(qslot[0]), qhi = __builtin_amdgcn_readfirstlane(qslot[1]);
+        const unsigned long long q = ((unsigned long long)qhi << 32) | qlo;
+        if ((q >> 24) != (p.q_tag >> 24)) break;            // (a foreign tag: never within one launch's lifetime)
+        item = (int)gridDim.x + (int)(q & 0xffffffull);
+        if (item >= p.n_items) break;
+    }
+    }   // items
 
     if (MODE == HM_MODE_TOPK) {
         // one 64-bit atomic per wave for the sure count
@@ -660,6 +695,7 @@ static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, h
     size_t lds = ((BF ? HM_DIST_BF16 : 1) + 1) * ppw * WPB * 1024;
     lds += (size_t)32 * row_bytes;                                          // slack behind the ring: the early request of "the next group's" fragment
     if (MODE == HM_MODE_HIST) lds += sizeof(uint32_t) * HM_HIST_BINS;      // (HIST mode keeps its bins there; they are only read by that request)
+    lds += 16;                                                              // the item queue's broadcast word
     const void* fn = reinterpret_cast<const void*>(&hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>);
     if (lds > 48 * 1024 && e->attr_done.find(fn) == e->attr_done.end()) {     // per engine (= per device), not process-wide
         hipError_t st = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -668,7 +704,26 @@ static hipError_t hm_launch_scan_t(hm_engine* e, const ScanArgs& a, dim3 grid, h
     }
     // timed launches carry their events in the dispatch itself (start / stop timestamps of this kernel): a pair of
     // hipEventRecord calls around it costs two ~6 us bubbles on the stream
-    const ScanArgs& b = a;
+    ScanArgs b = a;
+    b.n_items = (int)grid.x;
+    b.dyn = 0;
+    // item queue (ScanArgs::dyn): bf16 form (measured: profiles/r03g_ab_item_queue_*; the fp32 form keeps one block per item)
+    if (e->dyn_queue && BF && MODE != HM_MODE_HIST && grid.x < (1u << 24)) {
+        auto it = e->scan_slots.find(fn);
+        if (it == e->scan_slots.end()) {
+            int per_cu = 0;
+            hipError_t st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * WPB, lds);
+            if (st != hipSuccess) return st;
+            it = e->scan_slots.emplace(fn, std::max(1, per_cu) * e->n_cu).first;
+        }
+        const int slots = e->dyn_slots > 0 ? e->dyn_slots : it->second;
+        if ((int)grid.x > slots) {
+            grid.x = (unsigned)slots;
+            b.dyn = 1;
+            b.q_tag = (++e->scan_tag) << 24;
+            b.q_ctr = e->d_queue + 16 * ((b.ctr64 == e->d_ctr64) ? 0 : 1);      // one word per counter set (the pipelined loop alternates them)
+        }
+    }
     if (ev0 != nullptr || ev1 != nullptr) hipExtLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, ev0, ev1, 0, b);
     else hipLaunchKernelGGL((hm_scan_kernel<NG, SIGN, MODE, BF, TM, WPB, SUB>), grid, dim3(64 * WPB), lds, s, b);
     return hipGetLastError();
@@ -813,8 +868,9 @@ bool hm_prepare_scan(hm_engine* e, const Bounds& b, int64_t row_begin, int64_t r
     a.col_begin = (int)std::max<int64_t>(col_begin, 0);
     const int ct_lo = a.col_begin / cols;
     int nph = 1;
-    double share[HM_SCAN_PHASES] = {1.0, 0.0, 0.0, 0.0};
-    int div[HM_SCAN_PHASES] = {1, 1, 1, 1};
+    double share[HM_SCAN_PHASES] = {1.0};
+    int div[HM_SCAN_PHASES];
+    for (int q = 0; q < HM_SCAN_PHASES; ++q) div[q] = 1;
     if (ch >= 8 && nrb >= 16) {
         if (e->phases <= 2) {
             nph = 2;
