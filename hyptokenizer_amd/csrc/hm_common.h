@@ -112,7 +112,7 @@ struct ScanArgs {
     const uint32_t* order_seen;
     uint32_t order_need;
     uint32_t* order_fault;
-    // item queue (knob `dyn`, on by default for the bf16 form): the grid is only as large as the device holds at once; block b
+    // item queue (knob `dyn`, on by default): the grid is only as large as the device holds at once; block b
     // starts on item b and then draws further items of the SAME list, in order, from a device counter until n_items is
     // reached -- no dispatch gap between a slot's items, and the slots of a fast XCD take work that a static grid
     // (workgroup id mod 8 -> XCD) would have pinned to a slow one: 3 % off the launch at V = 50 k and 100 k.
@@ -172,7 +172,7 @@ struct hm_engine {
     int ph_div[HM_SCAN_PHASES] = {1, 2, 4, 8, 16, 32};
     unsigned long long* d_queue = nullptr; // item queue words: 2 x 128 B (one per counter set), never reset (ScanArgs::q_tag)
     int dyn_slots = 0;                    // knob `dyn_slots` (tests): resident-grid size of the item queue; 0 = what the device holds (occupancy x CUs)
-    bool dyn_queue = true;                // knob `dyn`: resident grid + in-order item queue (ScanArgs::dyn) for bf16 ARGMIN / TOPK launches
+    bool dyn_queue = true;                // knob `dyn`: resident grid + in-order item queue (ScanArgs::dyn) for ARGMIN / TOPK launches
     unsigned long long scan_tag = 0;      // launch tags of the item queue (monotonic per engine)
     std::map<const void*, int> scan_slots; // resident blocks per scan kernel instantiation on this engine's device
     int force_shape = -1;                 // HM_TUNE_SHAPE: bf16 block shape of every launch (tuning builds)

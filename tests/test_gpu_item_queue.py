@@ -1,7 +1,7 @@
 """GPU: the pair scan's item queue (a resident grid whose blocks draw items of the launch's list from a device counter,
 ScanArgs::dyn in hm_common.h) returns what the one-block-per-item grid returns, bit for bit, and what the oracle returns.
 
-The queue is the default for the bf16 prefilter when a launch has more items than the device holds blocks; the `dyn_slots`
+The queue is the default (both prefilter forms) when a launch has more items than the device holds blocks; the `dyn_slots`
 knob shrinks the resident grid so that small tables exercise it too (few blocks, each drawing many items, empty items
 left of the diagonal included)."""
 import numpy as np
@@ -17,6 +17,17 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
+FORM = "bf16"
+
+
+@pytest.fixture(params=["bf16", "f32"], autouse=True)
+def prefilter_form(request):
+    """both prefilter forms of the scan kernel (two sets of instantiations of the same queue code)"""
+    global FORM
+    FORM = request.param
+    yield request.param
+
+
 def _engine(X, knobs, max_rows=None, mode="lorentz"):
     from hyptokenizer_amd import _lib
     from hyptokenizer_amd.engine import MergeEngine
@@ -25,7 +36,7 @@ def _engine(X, knobs, max_rows=None, mode="lorentz"):
     max_rows = max_rows or n + 64
     table = torch.zeros((max_rows, d1), dtype=torch.float32, device="cuda")
     table[:n] = X.cuda()
-    eng = MergeEngine(max_rows, d1, mode, prefilter="bf16")
+    eng = MergeEngine(max_rows, d1, mode, prefilter=FORM)
     for k, v in knobs.items():
         _lib.check(L.hm_debug_set_knob(eng._h, k.encode(), float(v)))
     eng.set_table(table, n)

@@ -13,7 +13,7 @@ echo "[4] bench driver flags"; timeout -k 10 400 python bench.py --steps 20 --wa
 echo "[5] rocprofv3 kernel trace"; timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_prof.err; rc=$?; [ $rc -eq 0 ] || exit 15
 find $O/${TAG}_prof -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_bench_kernel_stats.csv \;
 rm -rf $O/${TAG}_prof/*/*kernel_trace.csv
-echo "[6] counter passes"; i=0
+echo "[6] counter passes"; i=0; mkdir -p $O/${TAG}_pmc
 for grp in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_WAVES"; do
     i=$((i+1))
