@@ -323,7 +323,8 @@ int hm_scan_totals(hm_engine* e, double* scan_ms, int64_t* pairs, int64_t* launc
 int hm_debug_force_cut(hm_engine* e, uint32_t cut_bits, int64_t k, float c);
 
 /* Test / tuning hook for the pair scan's work decomposition (results never depend on it): "big_rows" (512-row blocks for
- * launches covering at least the pairs of this many rows), "chunk", "tail", "tail_div", "shape", "incr_topk", "phases" / "ph_share0..2" / "ph_div1..3" (item list of the scan), "pipeline" (0: the standard loop
+ * launches covering at least the pairs of this many rows), "chunk", "tail", "tail_div", "shape", "incr_topk", "phases" / "ph_share0..4" / "ph_div1..5" (item list of the scan), "dyn" (0: one block per item instead of the resident grid
+ * that draws its items from a device counter) and "dyn_slots" (size of that resident grid; 0 = what the device holds), "pipeline" (0: the standard loop
  * strictly sequential), "pipeline_pairs", "pipe_fault_at", "exact_search" (1: every top-k / count through the prefilter-free
  * exact path that is otherwise the last resort of a search whose survivors fit no emission cut), "kc_even" (default knob only:
  * bf16 image rows padded to whole 16-slot k-steps).  hm_debug_set_default_knob applies to every

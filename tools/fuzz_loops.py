@@ -46,6 +46,8 @@ for t in range(cases):
         eng = MergeEngine(n + steps + 4, d + 1, mode, prefilter=form)
         _lib.check(L.hm_debug_set_knob(eng._h, b"pipeline", 0.0 if variant == "seq" else 1.0))
         _lib.check(L.hm_debug_set_knob(eng._h, b"pipeline_pairs", 0.0))
+        for kv in filter(None, os.environ.get("FUZZ_KNOBS", "").split(",")):      # e.g. FUZZ_KNOBS=dyn_slots=6: the scan's item queue on small tables
+            _lib.check(L.hm_debug_set_knob(eng._h, kv.split("=")[0].encode(), float(kv.split("=")[1])))
         eng.set_table(table, n)
         eng.set_token_lengths(lens)
         if variant == "incr":

@@ -1,6 +1,6 @@
 """Randomised GPU-vs-oracle parity sweep (development aid): python tools/fuzz_parity.py [CASES] [SEED]
 Random table sizes / widths / scales / thresholds / sign modes / prefilter forms / row ranges / curvatures;
-argmin, top-k and count must match the oracle bit for bit."""
+argmin, top-k and count must match the oracle bit for bit.  FUZZ_KNOBS="knob=value,..." adds default knobs to every case."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, "."); sys.path.insert(0, "oracle")
 from hyptokenizer_amd.engine import MergeEngine
@@ -19,6 +19,8 @@ for t in range(cases):
     _L.hm_debug_set_default_knob(None, 0.0, 1)
     if "512" in form: _L.hm_debug_set_default_knob(b"big_rows", 2.0, 0)
     if form.endswith("k112"): _L.hm_debug_set_default_knob(b"kc_even", 1.0, 0)
+    for kv in filter(None, os.environ.get("FUZZ_KNOBS", "").split(",")):      # e.g. FUZZ_KNOBS=dyn_slots=6: the scan's item queue on small tables too
+        _L.hm_debug_set_default_knob(kv.split("=")[0].encode(), float(kv.split("=")[1]), 0)
     if rng.random() < 0.12:                               # the prefilter-free path (hm_exact.hip) on an ordinary table
         _L.hm_debug_set_default_knob(b"exact_search", 1.0, 0); form += "+exact"
     X = lorentz_table(n, d, seed=int(rng.integers(1 << 30)), scale=scale)
